@@ -1,0 +1,159 @@
+/*
+ * vof2d.h -- C ABI of libvof2d_hip.so, the MI355X (gfx950) drop-in for the hot
+ * path of houkensjtu/taichi-2d-vof's 2dvof.py.
+ *
+ * The reference has no FFI: its boundary is the set of zero-argument
+ * @ti.kernel callables (2dvof.py:137,162,198,206,236,269,283,321,385,452),
+ * the module-global ti.field objects (2dvof.py:53-93) with
+ * .to_numpy()/.from_numpy() (2dvof.py:44,46,535,565) and the 0-D field
+ * sigma[None] (2dvof.py:28-29).  Each entry point below names the reference
+ * line range it replaces.  Plain pointers and sizes only; every function
+ * returns 0 on success or a negative VOF_E* code (message via
+ * vof_last_error).  No exceptions or aborts cross this boundary.
+ *
+ * Layout at the boundary (vof_get_field/vof_set_field): C-contiguous
+ * (row_hi-row_lo+1, ny+2) arrays of the handle's dtype, index [i - row_lo][j],
+ * ghosts included -- exactly what F.to_numpy() returns in the reference for
+ * the full domain (row_lo = 0, row_hi = nx+1).  The internal device pitch and
+ * padding are private (vof_field_view exposes them for zero-copy halo
+ * exchange).
+ *
+ * Threading: one host thread per handle; verbs enqueue asynchronously on the
+ * handle's HIP stream; vof_get_field, vof_get_counter, vof_sync and the
+ * timer functions synchronise that stream.
+ */
+#ifndef VOF2D_H
+#define VOF2D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOF_ABI_VERSION 1
+
+/* dtype of every field (2dvof.py:9 default_fp) */
+#define VOF_F64 0
+#define VOF_F32 1
+
+/* error codes */
+#define VOF_OK 0
+#define VOF_EINVAL (-1)  /* bad argument / unknown name / size mismatch */
+#define VOF_EHIP (-2)    /* a HIP runtime call failed (see vof_last_error) */
+#define VOF_ENOMEM (-3)
+#define VOF_ESTATE (-4)  /* call not valid in the handle's current state */
+
+/* width (rows) of the per-step deep halo a strip needs on each interior side:
+ * normals 1 + curvature 1 + predictor 1 + rhs 1(high side) + 10 Jacobi
+ * sweeps + update_uv 1(low side) + fct_x_sweep 3 (DESIGN.md "strips"). */
+#define VOF_HALO_ROWS(jacobi_iters) ((jacobi_iters) + 6)
+
+typedef struct vof2d_desc {
+  int32_t abi_version;    /* VOF_ABI_VERSION */
+  int32_t nx, ny;         /* global interior cells (2dvof.py:19-20) */
+  int32_t dtype;          /* VOF_F64 | VOF_F32 (2dvof.py:9) */
+  int32_t coord_cast_f32; /* 1: keep .astype(np.float32) of 2dvof.py:43,45 */
+  int32_t row_lo, row_hi; /* global rows stored by this handle, inclusive.
+                             Full domain: 0 .. nx+1.  A strip stores its owned
+                             rows plus halo rows. */
+  int32_t own_lo, own_hi; /* rows this handle owns (counters, residuals) */
+  int32_t jacobi_iters;   /* sweeps per step; 10 in 2dvof.py:521 */
+  int32_t device;         /* HIP device ordinal, -1 = current */
+  int32_t flags;          /* VOF_FLAG_* */
+  double Lx, Ly;          /* 2dvof.py:22-23 */
+  double rho_l, rho_g;    /* :24-25 */
+  double nu_l, nu_g;      /* :26-27 */
+  double sigma;           /* :28-29 (runtime, see vof_set_param) */
+  double gx, gy;          /* :30-31 */
+  double dt;              /* :33 */
+} vof2d_desc;
+
+#define VOF_FLAG_NO_GRAPH 1 /* vof_step launches kernels eagerly (no hipGraph) */
+
+typedef struct vof2d_ctx* vof2d_handle;
+
+/* Fill *d with the constants of 2dvof.py:19-33 for an nx x ny full domain. */
+int vof_desc_default(vof2d_desc* d, int32_t nx, int32_t ny, int32_t dtype);
+
+/* Allocate the fields of 2dvof.py:53-89 that are state or scratch of the hot
+ * path, zero-initialised (Taichi zero-fills; the solver relies on it,
+ * SURVEY 8c-S5).  stream: a hipStream_t to enqueue on, or NULL to create one. */
+int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out);
+int vof_destroy(vof2d_handle h);
+
+/* ---- the reference verbs (zero-argument @ti.kernel callables) ---- */
+int vof_set_init_F(vof2d_handle h, int32_t ic);     /* 2dvof.py:137-159 (+102-134) */
+int vof_set_BC(vof2d_handle h);                     /* :162-189 */
+int vof_cal_nu_rho(vof2d_handle h);                 /* :198-203 */
+int vof_get_normal_young(vof2d_handle h);           /* :283-309 */
+int vof_advect_upwind(vof2d_handle h);              /* :206-233 */
+/* n calls of solve_p_jacobi() (:236-266): rhs once, n Jacobi sweeps
+ * (ping-pong p/pt), result in p. */
+int vof_solve_p_jacobi(vof2d_handle h, int32_t n);
+int vof_update_uv(vof2d_handle h);                  /* :269-280 */
+int vof_fct_x_sweep(vof2d_handle h);                /* :321-382 */
+int vof_fct_y_sweep(vof2d_handle h);                /* :385-448 */
+/* :312-318, sweep order from istep parity (even: y then x) */
+int vof_solve_VOF_rudman(vof2d_handle h, int64_t istep);
+int vof_post_process_f(vof2d_handle h);             /* :452-455 */
+
+/* nsteps iterations of the solver part of the main loop, 2dvof.py:506-528
+ * (istep += 1 first; 10 Jacobi sweeps; x/y sweep alternation), using the fused
+ * kernel schedule.  rho/nu/kappa scratch is not materialised. */
+int vof_step(vof2d_handle h, int64_t nsteps);
+int vof_get_istep(vof2d_handle h, int64_t* istep);
+int vof_set_istep(vof2d_handle h, int64_t istep);
+
+/* Extension (not in the reference): Jacobi sweeps until
+ * max|p_new - p| over owned rows <= tol, checked every check_every sweeps,
+ * at most max_iters.  *residual is this handle's local value. */
+int vof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every,
+                         int32_t* iters_done, double* residual);
+/* one rhs build + n sweeps + local max|p_new - p| of the last sweep
+ * (building block for the distributed residual all-reduce). */
+int vof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual);
+
+/* ---- fields: F.to_numpy() / F.from_numpy() (2dvof.py:44,46,535,565) ----
+ * names: F u v p u_star v_star mx my kappa rho nu rhs */
+int vof_get_field(vof2d_handle h, const char* name, void* dst, size_t nbytes);
+int vof_set_field(vof2d_handle h, const char* name, const void* src, size_t nbytes);
+/* rows [g0, g1] (global indices, inclusive) of a field, dense (g1-g0+1, ny+2) */
+int vof_get_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, void* dst, size_t nbytes);
+int vof_set_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, const void* src,
+                 size_t nbytes);
+/* device view for zero-copy halo exchange: element (i, j) lives at
+ * base + ((i - row_lo) * pitch + col0 + j) * elem_size */
+int vof_field_view(vof2d_handle h, const char* name, void** base, int64_t* pitch, int64_t* col0,
+                   int64_t* nrows);
+/* device-to-device copy of rows [g0, g1] of `name` from src into dst (same
+ * nx, ny, dtype; rows must be stored by both).  Used for single-GPU strip
+ * emulation; across GPUs the exchange is RCCL send/recv on vof_field_view. */
+int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t g0, int32_t g1);
+
+/* ---- scalars ---- */
+/* settable: sigma (sigma[None], :28-29).  readable: sigma dt dx dy dxi dyi
+ * dxi2 dyi2 Lx Ly rho_l rho_g nu_l nu_g gx gy (Python-double values). */
+int vof_set_param(vof2d_handle h, const char* name, double value);
+int vof_get_param(vof2d_handle h, const char* name, double* value);
+/* "courant_violations": number of faces that tripped the prints at
+ * 2dvof.py:274-275,279-280 since creation (owned rows only). */
+int vof_get_counter(vof2d_handle h, const char* name, int64_t* value);
+
+/* ---- sync / timing / errors ---- */
+int vof_sync(vof2d_handle h);
+/* hipEvent pair on the handle's stream */
+int vof_timer_start(vof2d_handle h);
+int vof_timer_stop(vof2d_handle h, float* ms); /* records, synchronises, returns elapsed */
+/* n Jacobi sweeps only (no rhs build), timed with hipEvents on the handle's
+ * stream; *ms_per_sweep = elapsed / n.  p is advanced by n sweeps. */
+int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep);
+const char* vof_last_error(vof2d_handle h);
+/* "hip-gfx950" for the product library, "cpu-oracle" for oracle/ */
+const char* vof_backend(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOF2D_H */
