@@ -45,9 +45,11 @@ extern "C" {
 #define VOF_ENOMEM (-3)
 #define VOF_ESTATE (-4)  /* call not valid in the handle's current state */
 
-/* width (rows) of the per-step deep halo a strip needs on each interior side:
- * normals 1 + curvature 1 + predictor 1 + rhs 1(high side) + 10 Jacobi
- * sweeps + update_uv 1(low side) + fct_x_sweep 3 (DESIGN.md "strips"). */
+/* width (rows) of the per-step deep halo a strip needs on each interior side.
+ * Dependency radius of one step in i (DESIGN.md "strips"): normals 1 +
+ * curvature 1 + predictor 1 + n Jacobi sweeps + update_uv 1 + fct_x_sweep 2
+ * (velocity) = n + 5 on the low side, rhs 1 + n + fct_x_sweep 3 + ... = n + 5
+ * on the high side; one spare row is allocated. */
 #define VOF_HALO_ROWS(jacobi_iters) ((jacobi_iters) + 6)
 
 typedef struct vof2d_desc {

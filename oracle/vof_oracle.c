@@ -158,7 +158,29 @@ int ovof_get_normal_young(vof2d_handle h) { if (!h) return VOF_EINVAL; DISPATCH(
 int ovof_advect_upwind(vof2d_handle h) { if (!h) return VOF_EINVAL; DISPATCH(h, advect_upwind); return VOF_OK; }
 int ovof_solve_p_jacobi(vof2d_handle h, int32_t n) {
   if (!h || n < 0) return VOF_EINVAL;
-  for (int k = 0; k < n; ++k) DISPATCH(h, solve_p_jacobi);
+  for (int k = 0; k < n; ++k) DISPATCH(h, solve_p_jacobi, NULL);
+  return VOF_OK;
+}
+/* Extension: n sweeps, *residual = max|p_new - p| over owned rows of the last one. */
+int ovof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual) {
+  (void)build_rhs; /* the oracle recomputes the (iteration-invariant) rhs in every sweep, like :239-241 */
+  if (!h || !residual || n < 1) return VOF_EINVAL;
+  for (int k = 0; k < n; ++k) DISPATCH(h, solve_p_jacobi, k == n - 1 ? residual : NULL);
+  return VOF_OK;
+}
+int ovof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every, int32_t* iters_done,
+                          double* residual) {
+  if (!h || !iters_done || !residual || max_iters < 1 || check_every < 1) return VOF_EINVAL;
+  int done = 0;
+  double r = 0.0;
+  while (done < max_iters) {
+    int n = check_every < max_iters - done ? check_every : max_iters - done;
+    ovof_jacobi_sweeps_residual(h, n, 1, &r);
+    done += n;
+    if (r <= tol) break;
+  }
+  *iters_done = done;
+  *residual = r;
   return VOF_OK;
 }
 int ovof_update_uv(vof2d_handle h) { if (!h) return VOF_EINVAL; DISPATCH(h, update_uv); return VOF_OK; }

@@ -1,0 +1,694 @@
+// vof2d_api.hip -- C ABI (include/vof2d.h) over the gfx950 kernels.
+//
+// Host-side runtime of the drop-in: owns the device arena, the HIP stream, the
+// per-step launch schedule (eager or hipGraph replay) and the pitched
+// host<->device copies behind to_numpy()/from_numpy().  No CPU compute path
+// exists here: every verb is a kernel launch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/vof2d.h"
+#include "vof2d_kernels.h"
+
+using namespace vof;
+
+namespace {
+
+enum FieldId { fF = 0, fF2, fU, fV, fP, fPT, fUS, fVS, fMX, fMY, fKAPPA, fRHO, fNU, fRHS, NFIELDS };
+const char* const kFieldNames[NFIELDS] = {"F", "F2", "u", "v", "p", "pt", "u_star", "v_star",
+                                          "mx", "my", "kappa", "rho", "nu", "rhs"};
+
+struct ConstsD {  // Python-double values
+  double dt, dx, dy, dxi, dyi, dxi2, dyi2, rho_l, rho_g, nu_l, nu_g, sigma, gx, gy;
+  double nrm_x, nrm_y, kap_x, kap_y, dxdy, dtdy, dtdx, cfl_x, cfl_y, half_dx, half_dy, sqrt2dx, tiny;
+  double ic1_x2, ic1_y2, ic_r, ic_cx, ic2_cy, ic3_cy, ic3_pool;
+};
+
+double host_node_coord(double L, int n, int k, int cast_f32) {
+  // k-th entry of hstack((0, linspace(0, L, n+1), L)) [.astype(float32)], 2dvof.py:43-46
+  double v = k == 0 ? 0.0 : (k >= n + 1 ? L : (double)(k - 1) * (L / (double)n));
+  if (cast_f32) v = (double)(float)v;
+  return v;
+}
+
+void compute_consts(const vof2d_desc& d, ConstsD& c) {
+  const int cast = d.coord_cast_f32 || d.dtype == VOF_F32;  // an f32 field rounds the coordinates anyway
+  // 2dvof.py:47-50: Python-scope reads of x[imin+2], x[imin+1] -> Python doubles
+  const double dx = host_node_coord(d.Lx, d.nx, 3, cast) - host_node_coord(d.Lx, d.nx, 2, cast);
+  const double dy = host_node_coord(d.Ly, d.ny, 3, cast) - host_node_coord(d.Ly, d.ny, 2, cast);
+  const double dxi = 1 / dx, dyi = 1 / dy;
+  c.dt = d.dt; c.dx = dx; c.dy = dy; c.dxi = dxi; c.dyi = dyi;
+  c.dxi2 = std::pow(dxi, 2.0);  // dxi ** 2  (:216)
+  c.dyi2 = std::pow(dyi, 2.0);
+  c.rho_l = d.rho_l; c.rho_g = d.rho_g; c.nu_l = d.nu_l; c.nu_g = d.nu_g;
+  c.sigma = d.sigma; c.gx = d.gx; c.gy = d.gy;
+  c.nrm_x = -1 / (2 * dx);  // :287
+  c.nrm_y = -1 / (2 * dy);
+  c.kap_x = 1 / dx / 2;     // :308
+  c.kap_y = 1 / dy / 2;
+  c.dxdy = dx * dy;         // :324
+  c.dtdy = d.dt * dy;       // :324
+  c.dtdx = d.dt * dx;       // :388
+  c.cfl_x = 0.25 * dx;      // :274
+  c.cfl_y = 0.25 * dy;      // :279
+  c.half_dx = dx / 2;       // :105
+  c.half_dy = dy / 2;
+  c.sqrt2dx = std::sqrt(2.0) * dx;  // :131
+  c.tiny = 1e-10;           // :300
+  c.ic1_x2 = d.Lx / 3;      // :141
+  c.ic1_y2 = d.Ly / 2;      // :143
+  c.ic_r = d.Lx / 12;       // :150
+  c.ic_cx = d.Lx / 2;       // :151
+  c.ic2_cy = 2 * (d.Lx / 12);         // :151
+  c.ic3_cy = d.Ly - 3 * (d.Lx / 12);  // :155
+  c.ic3_pool = d.Ly * 0.37;           // :157
+}
+
+template <typename T>
+Consts<T> round_consts(const ConstsD& s) {
+  Consts<T> c;
+#define R1(n) c.n = (T)s.n
+  R1(dt); R1(dx); R1(dy); R1(dxi); R1(dyi); R1(dxi2); R1(dyi2); R1(rho_l); R1(rho_g); R1(nu_l); R1(nu_g);
+  R1(sigma); R1(gx); R1(gy); R1(nrm_x); R1(nrm_y); R1(kap_x); R1(kap_y); R1(dxdy); R1(dtdy); R1(dtdx);
+  R1(cfl_x); R1(cfl_y); R1(half_dx); R1(half_dy); R1(sqrt2dx); R1(tiny);
+  R1(ic1_x2); R1(ic1_y2); R1(ic_r); R1(ic_cx); R1(ic2_cy); R1(ic3_cy); R1(ic3_pool);
+#undef R1
+  return c;
+}
+
+}  // namespace
+
+struct vof2d_ctx {
+  vof2d_desc d;
+  ConstsD cd;
+  Geom g;
+  int V;          // elements per lane
+  size_t esz;     // sizeof(T)
+  int nty;        // y-sweep tiles
+  size_t field_elems;
+  char* arena = nullptr;
+  void* fld[NFIELDS];
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int device = 0;
+  unsigned long long* d_courant = nullptr;  // device counters: [0] courant, [1] residual bits
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int64_t istep = 0;
+  int rows_override = 0;
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};  // [istep parity]
+  char err[512];
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      snprintf((h)->err, sizeof((h)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call,          \
+               hipGetErrorString(e_));                                                           \
+      return VOF_EHIP;                                                                           \
+    }                                                                                            \
+  } while (0)
+
+int fail(vof2d_ctx* h, int code, const char* msg) {
+  if (h) snprintf(h->err, sizeof(h->err), "%s", msg);
+  return code;
+}
+
+int field_id(const char* name) {
+  if (!name) return -1;
+  for (int k = 0; k < NFIELDS; ++k)
+    if (!strcmp(name, kFieldNames[k])) return k;
+  return -1;
+}
+
+template <typename T> T* F_(vof2d_ctx* h, int id) { return reinterpret_cast<T*>(h->fld[id]); }
+
+// rows per wave chunk: enough waves to fill 256 CUs several times over, but
+// long enough chunks that the 2 halo rows of a 3-row stencil stay a small
+// fraction of the traffic.
+int pick_rows(const vof2d_ctx* h, int ntiles) {
+  if (h->rows_override > 0) return h->rows_override;
+  const int rows = h->g.ihi - h->g.ilo + 1;
+  long waves_at_1 = (long)rows * ntiles;
+  int R = (int)(waves_at_1 / 4096);
+  if (R < 4) R = 4;
+  if (R > 32) R = 32;
+  return R;
+}
+inline unsigned blocks_for(const vof2d_ctx* h, int ntiles, int R) {
+  const int rows = h->g.ihi - h->g.ilo + 1;
+  const long chunks = (rows + R - 1) / R;
+  const long waves = chunks * ntiles;
+  return (unsigned)((waves + 3) / 4);
+}
+
+// ------------------------------------------------------------------ launches
+template <typename T>
+struct L {
+  static constexpr int V = VecWidth<T>::V;
+  static Consts<T> C(vof2d_ctx* h) { return round_consts<T>(h->cd); }
+
+  static void init_F(vof2d_ctx* h, int ic) {
+    dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
+    hipLaunchKernelGGL(k_init_F<T>, grid, dim3(256), 0, h->stream, h->g, C(h), F_<T>(h, fF), F_<T>(h, fF2), ic,
+                       h->d.Lx, h->d.Ly, (int)(h->d.coord_cast_f32 || h->d.dtype == VOF_F32));
+  }
+  template <bool STORED>
+  static void set_bc(vof2d_ctx* h) {
+    const int nr = h->g.row_hi - h->g.row_lo + 1;
+    const int n = nr > h->g.ny + 2 ? nr : h->g.ny + 2;
+    hipLaunchKernelGGL((k_set_bc<T, STORED>), dim3((n + 255) / 256), dim3(256), 0, h->stream, h->g, F_<T>(h, fU),
+                       F_<T>(h, fV), F_<T>(h, fF), F_<T>(h, fF2), F_<T>(h, fP), F_<T>(h, fRHO));
+  }
+  static void nu_rho(vof2d_ctx* h) {
+    dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
+    hipLaunchKernelGGL(k_nu_rho<T>, grid, dim3(256), 0, h->stream, h->g, C(h), F_<T>(h, fF), F_<T>(h, fRHO),
+                       F_<T>(h, fNU));
+  }
+  static void post(vof2d_ctx* h) {
+    dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
+    hipLaunchKernelGGL(k_post<T>, grid, dim3(256), 0, h->stream, h->g, F_<T>(h, fF), F_<T>(h, fF2));
+  }
+  static void normals(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    hipLaunchKernelGGL((k_normals<T, V>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g, C(h),
+                       F_<T>(h, fF), F_<T>(h, fMX), F_<T>(h, fMY), R);
+  }
+  static void kappa(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    hipLaunchKernelGGL((k_kappa<T, V>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g, C(h),
+                       F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fKAPPA), R);
+  }
+  template <bool STORED>
+  static void predictor(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    hipLaunchKernelGGL((k_predictor<T, V, STORED>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream,
+                       h->g, C(h), F_<T>(h, fU), F_<T>(h, fV), F_<T>(h, fKAPPA), F_<T>(h, fF), F_<T>(h, fRHO),
+                       F_<T>(h, fNU), F_<T>(h, fUS), F_<T>(h, fVS), R);
+  }
+  template <bool STORED>
+  static void rhs(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    hipLaunchKernelGGL((k_rhs<T, V, STORED>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g,
+                       C(h), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fF), F_<T>(h, fRHO), F_<T>(h, fRHS), R);
+  }
+  // one sweep src -> dst
+  template <bool RESID>
+  static void jacobi(vof2d_ctx* h, int src, int dst) {
+    const int R = pick_rows(h, h->g.ntj);
+    hipLaunchKernelGGL((k_jacobi<T, V, 2, RESID>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream,
+                       h->g, C(h), F_<T>(h, src), F_<T>(h, fRHS), F_<T>(h, dst), R, h->d_courant + 1);
+  }
+  template <bool STORED>
+  static void correct(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    hipLaunchKernelGGL((k_correct<T, V, STORED>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g,
+                       C(h), F_<T>(h, fP), F_<T>(h, fF), F_<T>(h, fRHO), F_<T>(h, fUS), F_<T>(h, fVS),
+                       F_<T>(h, fU), F_<T>(h, fV), R, h->d_courant);
+  }
+  // sweeps read fld[fF], write fld[fF2]; the caller swaps the two afterwards
+  template <bool POST>
+  static void fct_x(vof2d_ctx* h) {
+    const int R = h->rows_override > 0 ? h->rows_override : 64;
+    hipLaunchKernelGGL((k_fct_x<T, V, POST>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g,
+                       C(h), F_<T>(h, fF), F_<T>(h, fU), F_<T>(h, fF2), R);
+  }
+  template <bool POST>
+  static void fct_y(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->nty);
+    hipLaunchKernelGGL((k_fct_y<T, V, POST>), dim3(blocks_for(h, h->nty, R)), dim3(256), 0, h->stream, h->g, C(h),
+                       F_<T>(h, fF), F_<T>(h, fV), F_<T>(h, fF2), R, h->nty);
+  }
+};
+
+void swap_F(vof2d_ctx* h) {
+  void* t = h->fld[fF];
+  h->fld[fF] = h->fld[fF2];
+  h->fld[fF2] = t;
+}
+
+template <typename T, bool POST>
+void sweep_x(vof2d_ctx* h) { L<T>::template fct_x<POST>(h); swap_F(h); }
+template <typename T, bool POST>
+void sweep_y(vof2d_ctx* h) { L<T>::template fct_y<POST>(h); swap_F(h); }
+
+// interior copy src -> dst (only used to keep p in place for odd sweep counts)
+template <typename T>
+__global__ void k_copy_interior(Geom g, const T* __restrict__ s, T* __restrict__ d) {
+  const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g.ilo + blockIdx.y;
+  if (j > g.ny || i > g.ihi) return;
+  const size_t o = at(g, i, j);
+  d[o] = s[o];
+}
+
+// n Jacobi sweeps starting from fld[fP]; the result ends in fld[fP] (no pointer swap, so
+// p's ghost cells keep their set_BC values like the reference's copy-back loop :265-266).
+template <typename T>
+void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
+  if (n <= 0) return;
+  int k = 0;
+  if (n & 1) {  // odd: one sweep into pt, copy interior back, then an even number of sweeps
+    if (n == 1 && resid_last) L<T>::template jacobi<true>(h, fP, fPT); else L<T>::template jacobi<false>(h, fP, fPT);
+    dim3 grid((h->g.ny + 255) / 256, h->g.ihi - h->g.ilo + 1);
+    hipLaunchKernelGGL(k_copy_interior<T>, grid, dim3(256), 0, h->stream, h->g, F_<T>(h, fPT), F_<T>(h, fP));
+    k = 1;
+  }
+  for (; k < n; k += 2) {
+    L<T>::template jacobi<false>(h, fP, fPT);
+    if (k + 2 >= n && resid_last) L<T>::template jacobi<true>(h, fPT, fP); else L<T>::template jacobi<false>(h, fPT, fP);
+  }
+}
+
+// the fused per-step schedule, 2dvof.py:506-528 (DESIGN.md "schedule")
+template <typename T>
+void enqueue_step(vof2d_ctx* h, int64_t istep) {
+  // cal_nu_rho (:513) is folded into its consumers: rho/nu = f(F[i,j]) recomputed per cell
+  L<T>::normals(h);                       // :514 loop 1
+  L<T>::kappa(h);                         // :514 loop 2
+  L<T>::template predictor<false>(h);     // :517
+  L<T>::template set_bc<false>(h);        // :518
+  L<T>::template rhs<false>(h);           // :521-522, rhs part (iteration invariant)
+  jacobi_n<T>(h, h->d.jacobi_iters, false);  // :521-522
+  L<T>::template correct<false>(h);       // :524
+  L<T>::template set_bc<false>(h);        // :525
+  if (istep % 2 == 0) {                   // :526, :312-318; post_process_f (:527) fused into the 2nd sweep
+    sweep_y<T, false>(h);
+    sweep_x<T, true>(h);
+  } else {
+    sweep_x<T, false>(h);
+    sweep_y<T, true>(h);
+  }
+  L<T>::template set_bc<false>(h);        // :528
+}
+
+int ensure_ok(vof2d_ctx* h) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(h->err, sizeof(h->err), "kernel launch failed: %s", hipGetErrorString(e));
+    return VOF_EHIP;
+  }
+  return VOF_OK;
+}
+
+#define DISPATCH_T(h, expr_d, expr_f) \
+  do { if ((h)->d.dtype == VOF_F64) { expr_d; } else { expr_f; } } while (0)
+
+int copy_rows_host(vof2d_ctx* h, int id, int g0, int g1, void* host, size_t nbytes, bool to_host) {
+  if (g0 < h->d.row_lo || g1 > h->d.row_hi || g1 < g0) return fail(h, VOF_EINVAL, "row range not stored by this handle");
+  const size_t width = (size_t)(h->g.ny + 2) * h->esz;
+  const size_t rows = (size_t)(g1 - g0 + 1);
+  if (nbytes != width * rows) return fail(h, VOF_EINVAL, "buffer size does not match (rows, ny+2) of the field dtype");
+  char* dev = reinterpret_cast<char*>(h->fld[id]) + ((size_t)(g0 - h->d.row_lo) * h->g.pitch + h->g.col0) * h->esz;
+  const size_t dpitch = (size_t)h->g.pitch * h->esz;
+  if (to_host)
+    HIPCHK(h, hipMemcpy2DAsync(host, width, dev, dpitch, width, rows, hipMemcpyDeviceToHost, h->stream));
+  else
+    HIPCHK(h, hipMemcpy2DAsync(dev, dpitch, host, width, width, rows, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return VOF_OK;
+}
+
+void destroy_graphs(vof2d_ctx* h) {
+  for (int k = 0; k < 2; ++k)
+    if (h->gexec[k]) { (void)hipGraphExecDestroy(h->gexec[k]); h->gexec[k] = nullptr; }
+}
+
+}  // namespace
+
+// =============================================================== C ABI
+extern "C" {
+
+int vof_desc_default(vof2d_desc* d, int32_t nx, int32_t ny, int32_t dtype) {
+  if (!d || nx < 3 || ny < 3 || (dtype != VOF_F64 && dtype != VOF_F32)) return VOF_EINVAL;
+  memset(d, 0, sizeof(*d));
+  d->abi_version = VOF_ABI_VERSION;
+  d->nx = nx; d->ny = ny; d->dtype = dtype; d->coord_cast_f32 = 1;
+  d->row_lo = 0; d->row_hi = nx + 1; d->own_lo = 1; d->own_hi = nx;
+  d->jacobi_iters = 10; d->device = -1; d->flags = 0;
+  // 2dvof.py:22-33
+  d->Lx = 0.1; d->Ly = 0.1; d->rho_l = 1000.0; d->rho_g = 50.0; d->nu_l = 1.0e-6; d->nu_g = 1.5e-5;
+  d->sigma = 0.007; d->gx = 0; d->gy = -5; d->dt = 4e-6;
+  return VOF_OK;
+}
+
+int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
+  if (!d || !out || d->abi_version != VOF_ABI_VERSION) return VOF_EINVAL;
+  if (d->nx < 3 || d->ny < 3 || d->row_lo < 0 || d->row_hi > d->nx + 1 || d->row_hi - d->row_lo < 2) return VOF_EINVAL;
+  if (d->dtype != VOF_F64 && d->dtype != VOF_F32) return VOF_EINVAL;
+  if (d->jacobi_iters < 0) return VOF_EINVAL;
+  vof2d_ctx* h = new (std::nothrow) vof2d_ctx();
+  if (!h) return VOF_ENOMEM;
+  h->err[0] = 0;
+  h->d = *d;
+  compute_consts(*d, h->cd);
+  h->esz = d->dtype == VOF_F64 ? 8 : 4;
+  h->V = 16 / (int)h->esz;
+  const int W = 64 * h->V;
+  Geom& g = h->g;
+  g.nx = d->nx; g.ny = d->ny; g.row_lo = d->row_lo; g.row_hi = d->row_hi;
+  g.ilo = d->row_lo + 1 > 1 ? d->row_lo + 1 : 1;
+  g.ihi = d->row_hi - 1 < d->nx ? d->row_hi - 1 : d->nx;
+  g.own_lo = d->own_lo; g.own_hi = d->own_hi;
+  g.wall_lo = d->row_lo == 0; g.wall_hi = d->row_hi == d->nx + 1;
+  g.ntj = (d->ny + W - 1) / W;
+  h->nty = (d->ny + (W - 8) - 1) / (W - 8);
+  const int align = 128 / (int)h->esz;  // elements per 128 bytes
+  g.col0 = align - 1;                   // j = 1 lands on a 128-byte boundary
+  // furthest column any lane touches: marching tiles read j0+V (right neighbour) of the last
+  // tile; y-sweep tiles start at -3 + k*(W-8) and span W columns.
+  long maxcol = 1L + (long)g.ntj * W + h->V;
+  long ycol = -3L + (long)(h->nty - 1) * (W - 8) + W + h->V;
+  if (ycol > maxcol) maxcol = ycol;
+  if (maxcol < d->ny + 2) maxcol = d->ny + 2;
+  g.pitch = ((g.col0 + maxcol + 1 + align - 1) / align) * align;
+  const size_t nrows = (size_t)(d->row_hi - d->row_lo + 1);
+  h->field_elems = nrows * (size_t)g.pitch + (size_t)align;  // + one 128-byte tail pad
+  const char* ev = getenv("VOF2D_ROWS");
+  h->rows_override = ev ? atoi(ev) : 0;
+
+  int rc = VOF_OK;
+  do {
+    if (d->device >= 0) {
+      if (hipSetDevice(d->device) != hipSuccess) { rc = VOF_EHIP; break; }
+    }
+    if (hipGetDevice(&h->device) != hipSuccess) { rc = VOF_EHIP; break; }
+    if (stream) {
+      h->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+      if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = VOF_EHIP; break; }
+      h->own_stream = true;
+    }
+    const size_t bytes = h->field_elems * h->esz * NFIELDS;
+    if (hipMalloc(reinterpret_cast<void**>(&h->arena), bytes) != hipSuccess) { rc = VOF_ENOMEM; break; }
+    if (hipMemsetAsync(h->arena, 0, bytes, h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
+    for (int k = 0; k < NFIELDS; ++k) h->fld[k] = h->arena + (size_t)k * h->field_elems * h->esz;
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_courant), 2 * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
+    if (hipMemsetAsync(h->d_courant, 0, 2 * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = VOF_EHIP; break; }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
+  } while (0);
+  if (rc != VOF_OK) {
+    (void)hipGetLastError();
+    vof_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return VOF_OK;
+}
+
+int vof_destroy(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  destroy_graphs(h);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->d_courant) (void)hipFree(h->d_courant);
+  if (h->arena) (void)hipFree(h->arena);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return VOF_OK;
+}
+
+int vof_set_init_F(vof2d_handle h, int32_t ic) {
+  if (!h) return VOF_EINVAL;
+  if (ic < 1 || ic > 3) return fail(h, VOF_EINVAL, "ic must be 1, 2 or 3 (2dvof.py:13)");
+  DISPATCH_T(h, L<double>::init_F(h, ic), L<float>::init_F(h, ic));
+  return ensure_ok(h);
+}
+int vof_set_BC(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  DISPATCH_T(h, L<double>::set_bc<true>(h), L<float>::set_bc<true>(h));
+  return ensure_ok(h);
+}
+int vof_cal_nu_rho(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  DISPATCH_T(h, L<double>::nu_rho(h), L<float>::nu_rho(h));
+  return ensure_ok(h);
+}
+int vof_get_normal_young(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  DISPATCH_T(h, (L<double>::normals(h), L<double>::kappa(h)), (L<float>::normals(h), L<float>::kappa(h)));
+  return ensure_ok(h);
+}
+int vof_advect_upwind(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  DISPATCH_T(h, L<double>::predictor<true>(h), L<float>::predictor<true>(h));
+  return ensure_ok(h);
+}
+int vof_solve_p_jacobi(vof2d_handle h, int32_t n) {
+  if (!h) return VOF_EINVAL;
+  if (n < 0) return fail(h, VOF_EINVAL, "n must be >= 0");
+  if (n == 0) return VOF_OK;
+  DISPATCH_T(h, (L<double>::rhs<true>(h), jacobi_n<double>(h, n, false)),
+             (L<float>::rhs<true>(h), jacobi_n<float>(h, n, false)));
+  return ensure_ok(h);
+}
+int vof_update_uv(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  DISPATCH_T(h, L<double>::correct<true>(h), L<float>::correct<true>(h));
+  return ensure_ok(h);
+}
+int vof_fct_x_sweep(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  DISPATCH_T(h, (sweep_x<double, false>(h)), (sweep_x<float, false>(h)));
+  return ensure_ok(h);
+}
+int vof_fct_y_sweep(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  DISPATCH_T(h, (sweep_y<double, false>(h)), (sweep_y<float, false>(h)));
+  return ensure_ok(h);
+}
+int vof_solve_VOF_rudman(vof2d_handle h, int64_t istep) {
+  if (!h) return VOF_EINVAL;
+  int rc;
+  if (istep % 2 == 0) {
+    if ((rc = vof_fct_y_sweep(h))) return rc;
+    return vof_fct_x_sweep(h);
+  }
+  if ((rc = vof_fct_x_sweep(h))) return rc;
+  return vof_fct_y_sweep(h);
+}
+int vof_post_process_f(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  DISPATCH_T(h, L<double>::post(h), L<float>::post(h));
+  return ensure_ok(h);
+}
+
+int vof_step(vof2d_handle h, int64_t nsteps) {
+  if (!h) return VOF_EINVAL;
+  if (nsteps < 0) return fail(h, VOF_EINVAL, "nsteps must be >= 0");
+  const bool use_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
+  for (int64_t s = 0; s < nsteps; ++s) {
+    h->istep += 1;
+    const int par = (int)(h->istep & 1);
+    if (use_graph) {
+      if (!h->gexec[par]) {
+        // capture one step of this parity; both sweeps swap F twice so pointers are stable
+        hipGraph_t graph = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        DISPATCH_T(h, enqueue_step<double>(h, h->istep), enqueue_step<float>(h, h->istep));
+        HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
+        hipError_t e = hipGraphInstantiate(&h->gexec[par], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+          snprintf(h->err, sizeof(h->err), "hipGraphInstantiate: %s", hipGetErrorString(e));
+          return VOF_EHIP;
+        }
+      }
+      HIPCHK(h, hipGraphLaunch(h->gexec[par], h->stream));
+    } else {
+      DISPATCH_T(h, enqueue_step<double>(h, h->istep), enqueue_step<float>(h, h->istep));
+      int rc = ensure_ok(h);
+      if (rc) return rc;
+    }
+  }
+  return VOF_OK;
+}
+int vof_get_istep(vof2d_handle h, int64_t* istep) {
+  if (!h || !istep) return VOF_EINVAL;
+  *istep = h->istep;
+  return VOF_OK;
+}
+int vof_set_istep(vof2d_handle h, int64_t istep) {
+  if (!h) return VOF_EINVAL;
+  h->istep = istep;
+  return VOF_OK;
+}
+
+int vof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual) {
+  if (!h || !residual) return VOF_EINVAL;
+  if (n < 1) return fail(h, VOF_EINVAL, "n must be >= 1");
+  HIPCHK(h, hipMemsetAsync(h->d_courant + 1, 0, sizeof(unsigned long long), h->stream));
+  if (build_rhs) DISPATCH_T(h, L<double>::rhs<false>(h), L<float>::rhs<false>(h));
+  DISPATCH_T(h, jacobi_n<double>(h, n, true), jacobi_n<float>(h, n, true));
+  int rc = ensure_ok(h);
+  if (rc) return rc;
+  unsigned long long bits = 0;
+  HIPCHK(h, hipMemcpyAsync(&bits, h->d_courant + 1, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double r;
+  memcpy(&r, &bits, sizeof(r));
+  *residual = r;
+  return VOF_OK;
+}
+
+int vof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every, int32_t* iters_done,
+                         double* residual) {
+  if (!h || !iters_done || !residual) return VOF_EINVAL;
+  if (max_iters < 1 || check_every < 1) return fail(h, VOF_EINVAL, "max_iters and check_every must be >= 1");
+  int done = 0;
+  double r = 0.0;
+  bool first = true;
+  while (done < max_iters) {
+    int n = check_every < max_iters - done ? check_every : max_iters - done;
+    int rc = vof_jacobi_sweeps_residual(h, n, first ? 1 : 0, &r);
+    if (rc) return rc;
+    first = false;
+    done += n;
+    if (r <= tol) break;
+  }
+  *iters_done = done;
+  *residual = r;
+  return VOF_OK;
+}
+
+int vof_get_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, void* dst, size_t nbytes) {
+  if (!h || !dst) return VOF_EINVAL;
+  int id = field_id(name);
+  if (id < 0) return fail(h, VOF_EINVAL, "unknown field name");
+  return copy_rows_host(h, id, g0, g1, dst, nbytes, true);
+}
+int vof_set_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, const void* src, size_t nbytes) {
+  if (!h || !src) return VOF_EINVAL;
+  int id = field_id(name);
+  if (id < 0) return fail(h, VOF_EINVAL, "unknown field name");
+  int rc = copy_rows_host(h, id, g0, g1, const_cast<void*>(src), nbytes, false);
+  if (rc == VOF_OK && id == fF) rc = copy_rows_host(h, fF2, g0, g1, const_cast<void*>(src), nbytes, false);
+  return rc;
+}
+int vof_get_field(vof2d_handle h, const char* name, void* dst, size_t nbytes) {
+  if (!h) return VOF_EINVAL;
+  return vof_get_rows(h, name, h->d.row_lo, h->d.row_hi, dst, nbytes);
+}
+int vof_set_field(vof2d_handle h, const char* name, const void* src, size_t nbytes) {
+  if (!h) return VOF_EINVAL;
+  return vof_set_rows(h, name, h->d.row_lo, h->d.row_hi, src, nbytes);
+}
+int vof_field_view(vof2d_handle h, const char* name, void** base, int64_t* pitch, int64_t* col0, int64_t* nrows) {
+  if (!h) return VOF_EINVAL;
+  int id = field_id(name);
+  if (id < 0) return fail(h, VOF_EINVAL, "unknown field name");
+  if (base) *base = h->fld[id];
+  if (pitch) *pitch = h->g.pitch;
+  if (col0) *col0 = h->g.col0;
+  if (nrows) *nrows = h->d.row_hi - h->d.row_lo + 1;
+  return VOF_OK;
+}
+int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t g0, int32_t g1) {
+  if (!dst || !src) return VOF_EINVAL;
+  int id = field_id(name);
+  if (id < 0) return fail(dst, VOF_EINVAL, "unknown field name");
+  if (dst->d.ny != src->d.ny || dst->d.nx != src->d.nx || dst->d.dtype != src->d.dtype)
+    return fail(dst, VOF_EINVAL, "handles differ in nx, ny or dtype");
+  if (g1 < g0 || g0 < src->d.row_lo || g1 > src->d.row_hi || g0 < dst->d.row_lo || g1 > dst->d.row_hi)
+    return fail(dst, VOF_EINVAL, "rows not stored by both handles");
+  // both use the same pitch/col0 (functions of ny and dtype only): one contiguous block
+  const size_t off_s = (size_t)(g0 - src->d.row_lo) * src->g.pitch * src->esz;
+  const size_t off_d = (size_t)(g0 - dst->d.row_lo) * dst->g.pitch * dst->esz;
+  const size_t bytes = (size_t)(g1 - g0 + 1) * src->g.pitch * src->esz;
+  // order: after src's pending work, on dst's stream
+  HIPCHK(dst, hipEventRecord(src->ev1, src->stream));
+  HIPCHK(dst, hipStreamWaitEvent(dst->stream, src->ev1, 0));
+  HIPCHK(dst, hipMemcpyAsync(reinterpret_cast<char*>(dst->fld[id]) + off_d,
+                             reinterpret_cast<char*>(src->fld[id]) + off_s, bytes, hipMemcpyDeviceToDevice,
+                             dst->stream));
+  if (id == fF)
+    HIPCHK(dst, hipMemcpyAsync(reinterpret_cast<char*>(dst->fld[fF2]) + off_d,
+                               reinterpret_cast<char*>(src->fld[fF]) + off_s, bytes, hipMemcpyDeviceToDevice,
+                               dst->stream));
+  return VOF_OK;
+}
+
+int vof_set_param(vof2d_handle h, const char* name, double value) {
+  if (!h || !name) return VOF_EINVAL;
+  if (!strcmp(name, "sigma")) {  // sigma[None] = value (2dvof.py:28-29); constants are baked into graphs
+    h->d.sigma = value;
+    h->cd.sigma = value;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    destroy_graphs(h);
+    return VOF_OK;
+  }
+  if (!strcmp(name, "rows_per_wave")) {  // tuning knob (0 = heuristic)
+    h->rows_override = (int)value;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    destroy_graphs(h);
+    return VOF_OK;
+  }
+  return fail(h, VOF_EINVAL, "unknown or read-only parameter");
+}
+int vof_get_param(vof2d_handle h, const char* name, double* value) {
+  if (!h || !name || !value) return VOF_EINVAL;
+#define P(n) if (!strcmp(name, #n)) { *value = h->cd.n; return VOF_OK; }
+  P(sigma) P(dt) P(dx) P(dy) P(dxi) P(dyi) P(dxi2) P(dyi2) P(rho_l) P(rho_g) P(nu_l) P(nu_g) P(gx) P(gy)
+  P(nrm_x) P(nrm_y) P(kap_x) P(kap_y) P(dxdy) P(dtdy) P(dtdx) P(cfl_x) P(cfl_y) P(half_dx) P(half_dy)
+  P(sqrt2dx) P(tiny)
+#undef P
+  if (!strcmp(name, "Lx")) { *value = h->d.Lx; return VOF_OK; }
+  if (!strcmp(name, "Ly")) { *value = h->d.Ly; return VOF_OK; }
+  if (!strcmp(name, "pitch")) { *value = (double)h->g.pitch; return VOF_OK; }
+  if (!strcmp(name, "rows_per_wave")) { *value = (double)pick_rows(h, h->g.ntj); return VOF_OK; }
+  return fail(h, VOF_EINVAL, "unknown parameter");
+}
+int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
+  if (!h || !name || !value) return VOF_EINVAL;
+  if (!strcmp(name, "courant_violations")) {
+    unsigned long long v = 0;
+    HIPCHK(h, hipMemcpyAsync(&v, h->d_courant, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *value = (int64_t)v;
+    return VOF_OK;
+  }
+  return fail(h, VOF_EINVAL, "unknown counter");
+}
+
+int vof_sync(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ensure_ok(h);
+}
+int vof_timer_start(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  return VOF_OK;
+}
+int vof_timer_stop(vof2d_handle h, float* ms) {
+  if (!h || !ms) return VOF_EINVAL;
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return VOF_OK;
+}
+int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep) {
+  if (!h || !ms_per_sweep) return VOF_EINVAL;
+  if (n < 2 || (n & 1)) return fail(h, VOF_EINVAL, "n must be even and >= 2");
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  DISPATCH_T(h, jacobi_n<double>(h, n, false), jacobi_n<float>(h, n, false));
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_per_sweep = ms / (float)n;
+  return ensure_ok(h);
+}
+const char* vof_last_error(vof2d_handle h) { return h ? h->err : "null handle"; }
+const char* vof_backend(void) { return "hip-gfx950"; }
+
+}  // extern "C"

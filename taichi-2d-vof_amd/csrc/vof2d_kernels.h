@@ -1,0 +1,719 @@
+// vof2d_kernels.h -- hand-written gfx950 kernels for the 2-D VOF hot path.
+//
+// Every kernel cites the reference lines (/root/reference/2dvof.py) it
+// replaces.  Arithmetic follows the reference's Python expression order,
+// left to right, with FMA contraction disabled (-ffp-contract=off), so the
+// results equal the CPU oracle's value for value.
+//
+// All stencil kernels share one decomposition (vof2d_device.h): a wave owns
+// 64*V contiguous columns and marches along i with a register window.
+#pragma once
+#include "vof2d_device.h"
+
+namespace vof {
+
+// ------------------------------------------------------------------ helpers
+template <typename T, int V>
+struct Row {  // one row of a wave tile as seen by a lane: j0-1 | j0..j0+V-1 | j0+V
+  T l;
+  T c[V];
+  T r;
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void load_c(T (&c)[V], const T* __restrict__ p) {
+  Pack<T, V> k = *reinterpret_cast<const Pack<T, V>*>(p);
+#pragma unroll
+  for (int q = 0; q < V; ++q) c[q] = k.v[q];
+}
+template <typename T, int V>
+__device__ __forceinline__ void load_row(Row<T, V>& w, const T* __restrict__ p) {
+  load_c<T, V>(w.c, p);
+  w.l = p[-1];
+  w.r = p[V];
+}
+// store columns j0..j0+V-1 restricted to [jlo, jhi]
+template <typename T, int V>
+__device__ __forceinline__ void store_c(T* __restrict__ p, const T (&c)[V], int j0, int jlo, int jhi) {
+  if (j0 >= jlo && j0 + V - 1 <= jhi) {
+    Pack<T, V> k;
+#pragma unroll
+    for (int q = 0; q < V; ++q) k.v[q] = c[q];
+    *reinterpret_cast<Pack<T, V>*>(p) = k;
+  } else {
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      if (j0 + q >= jlo && j0 + q <= jhi) p[q] = c[q];
+  }
+}
+template <typename T, int V>
+__device__ __forceinline__ T left_of(const Row<T, V>& w, int q) { return q == 0 ? w.l : w.c[q - 1]; }
+template <typename T, int V>
+__device__ __forceinline__ T right_of(const Row<T, V>& w, int q) { return q == V - 1 ? w.r : w.c[q + 1]; }
+
+// wave -> (column tile, row chunk).  Rows [first, last] are split in chunks of R.
+template <int V>
+__device__ __forceinline__ bool wave_tile(const Geom& g, int first, int last, int R, int& j0, int& ra,
+                                          int& rb) {
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int tj = wave % g.ntj;
+  const int ch = wave / g.ntj;
+  j0 = 1 + tj * 64 * V + lane * V;
+  ra = first + ch * R;
+  rb = ra + R - 1 < last ? ra + R - 1 : last;
+  return ra <= last && j0 <= g.ny;
+}
+__device__ __forceinline__ size_t at(const Geom& g, int i, int j) {
+  return (size_t)(i - g.row_lo) * (size_t)g.pitch + (size_t)(g.col0 + j);
+}
+
+// ------------------------------------------------------------------ init
+// 2dvof.py:102-134 find_area
+template <typename T>
+__device__ T find_area(const Consts<T>& c, int i, int j, T cx, T cy, T r) {
+  T a;
+  T xct = (T)(i - 1) * c.dx + c.half_dx;
+  T yct = (T)(j - 1) * c.dy + c.half_dy;
+  T xlu = xct - c.half_dx, ylu = yct + c.half_dy;
+  T xld = xct - c.half_dx, yld = yct - c.half_dy;
+  T xru = xct + c.half_dx, yru = yct + c.half_dy;
+  T xrd = xct + c.half_dx, yrd = yct - c.half_dy;
+#define VOF_DIST(X, Y) dsqrt<T>(((X) - cx) * ((X) - cx) + ((Y) - cy) * ((Y) - cy))
+  T dct = VOF_DIST(xct, yct), dlu = VOF_DIST(xlu, ylu), dld = VOF_DIST(xld, yld), dru = VOF_DIST(xru, yru),
+    drd = VOF_DIST(xrd, yrd);
+#undef VOF_DIST
+  if (dlu > r && dld > r && dru > r && drd > r)
+    a = (T)1.0;
+  else if (dlu < r && dld < r && dru < r && drd < r)
+    a = (T)0.0;
+  else {
+    a = (T)0.5 + (T)0.5 * (dct - r) / c.sqrt2dx;
+    a = var3(a, (T)0, (T)1);
+  }
+  return a;
+}
+
+// node coordinate x[k] of 2dvof.py:43-46: hstack((0, linspace(0, L, n+1), L)).astype(f32)
+__device__ __forceinline__ double node_coord(double L, int n, int k, int cast_f32) {
+  double v = k == 0 ? 0.0 : (k >= n + 1 ? L : (double)(k - 1) * (L / (double)n));
+  if (cast_f32) v = (double)(float)v;
+  return v;
+}
+
+// 2dvof.py:137-159 set_init_F, all stored cells incl. ghosts; writes F and its sweep twin
+template <typename T>
+__global__ __launch_bounds__(256) void k_init_F(Geom g, Consts<T> c, T* __restrict__ F, T* __restrict__ F2,
+                                                 int ic, double Lx, double Ly, int cast_f32) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g.row_lo + blockIdx.y;
+  if (j > g.ny + 1 || i > g.row_hi) return;
+  const size_t o = at(g, i, j);
+  T val = F[o];
+  if (ic == 1) {
+    T xi = (T)node_coord(Lx, g.nx, i, cast_f32), yj = (T)node_coord(Ly, g.ny, j, cast_f32);
+    if (xi >= (T)0.0 && xi <= c.ic1_x2 && yj >= (T)0.0 && yj <= c.ic1_y2) val = (T)1.0;
+  } else if (ic == 2) {
+    val = find_area<T>(c, i, j, c.ic_cx, c.ic2_cy, c.ic_r);
+  } else {
+    val = (T)1.0 - find_area<T>(c, i, j, c.ic_cx, c.ic3_cy, c.ic_r);
+    T yj = (T)node_coord(Ly, g.ny, j, cast_f32);
+    if (yj < c.ic3_pool) val = (T)1.0;
+  }
+  F[o] = val;
+  F2[o] = val;
+}
+
+// ------------------------------------------------------------------ set_BC
+// 2dvof.py:162-189.  One thread per row index (loop 1) and per column index
+// (loop 2).  Loop 2 reads are redirected to cells loop 1 does not write, and
+// loop 1 skips the cells loop 2 overwrites, so one launch reproduces the
+// sequential "loop 1 then loop 2" result (corners take loop-2 values, S11).
+// F ghosts are mirrored into the sweep twin F2 (see k_fct_*).
+template <typename T, bool STORED>
+__global__ __launch_bounds__(256) void k_set_bc(Geom g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ F,
+                                                 T* __restrict__ F2, T* __restrict__ p, T* __restrict__ rho) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ny = g.ny, nx = g.nx;
+  // loop 1: row i
+  const int i = g.row_lo + t;
+  if (i <= g.row_hi) {
+    const bool wall_row = (g.wall_lo && i == 1) || (g.wall_hi && i == nx + 1);    // u zeroed by loop 2
+    const bool ghost_row = (g.wall_lo && i == 0) || (g.wall_hi && i == nx + 1);   // F,p,v,rho from loop 2
+    const size_t a0 = at(g, i, 0), a1 = at(g, i, 1), b0 = at(g, i, ny), b1 = at(g, i, ny + 1);
+    if (!wall_row) {
+      u[a0] = u[a1];
+      u[b1] = u[b0];
+    }
+    if (!ghost_row) {
+      v[a1] = (T)0;
+      v[b1] = (T)0;
+      T f0 = F[a1], f1 = F[b0];
+      F[a0] = f0; F[b1] = f1;
+      F2[a0] = f0; F2[b1] = f1;
+      p[a0] = p[a1];
+      p[b1] = p[b0];
+      if (STORED) {
+        rho[a0] = rho[a1];
+        rho[b1] = rho[b0];
+      }
+    }
+  }
+  // loop 2: column j
+  const int j = t;
+  if (j <= ny + 1) {
+    const int jj = j == 0 ? 1 : (j == ny + 1 ? ny : j);  // value loop 1 leaves at column j
+    const bool vz = (j == 1 || j == ny + 1);             // loop 1 zeroed v there
+    if (g.wall_lo) {
+      u[at(g, 1, j)] = (T)0;
+      v[at(g, 0, j)] = vz ? (T)0 : v[at(g, 1, j)];
+      T f = F[at(g, 1, jj)];
+      F[at(g, 0, j)] = f;
+      F2[at(g, 0, j)] = f;
+      p[at(g, 0, j)] = p[at(g, 1, jj)];
+      if (STORED) rho[at(g, 0, j)] = rho[at(g, 1, jj)];
+    }
+    if (g.wall_hi) {
+      u[at(g, nx + 1, j)] = (T)0;
+      v[at(g, nx + 1, j)] = vz ? (T)0 : v[at(g, nx, j)];
+      T f = F[at(g, nx, jj)];
+      F[at(g, nx + 1, j)] = f;
+      F2[at(g, nx + 1, j)] = f;
+      p[at(g, nx + 1, j)] = p[at(g, nx, jj)];
+      if (STORED) rho[at(g, nx + 1, j)] = rho[at(g, nx, jj)];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ cal_nu_rho
+// 2dvof.py:198-203 (verb only: the fused step recomputes rho/nu from F in place)
+template <typename T>
+__global__ __launch_bounds__(256) void k_nu_rho(Geom g, Consts<T> c, const T* __restrict__ F, T* __restrict__ rho,
+                                                 T* __restrict__ nu) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g.row_lo + blockIdx.y;
+  if (j > g.ny + 1 || i > g.row_hi) return;
+  const size_t o = at(g, i, j);
+  T f = F[o];
+  rho[o] = rho_of(c, f);
+  nu[o] = nu_of(c, f);
+}
+
+// 2dvof.py:452-455 post_process_f on all stored cells (verb); keeps the twin in sync
+template <typename T>
+__global__ __launch_bounds__(256) void k_post(Geom g, T* __restrict__ F, T* __restrict__ F2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g.row_lo + blockIdx.y;
+  if (j > g.ny + 1 || i > g.row_hi) return;
+  const size_t o = at(g, i, j);
+  T f = var3(F[o], (T)0, (T)1);
+  F[o] = f;
+  F2[o] = f;
+}
+
+// ------------------------------------------------------------------ normals
+// 2dvof.py:285-306 get_normal_young loop 1: F (3x3) -> mx, my on interior rows.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_normals(Geom g, Consts<T> c, const T* __restrict__ F, T* __restrict__ mx,
+                                                  T* __restrict__ my, int R) {
+  int j0, ra, rb;
+  if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
+  const T cxn = c.nrm_x, cyn = c.nrm_y;
+  size_t o = at(g, ra, j0);
+  Row<T, V> m, z, p;  // rows i-1, i, i+1
+  load_row<T, V>(m, F + o - g.pitch);
+  load_row<T, V>(z, F + o);
+  for (int i = ra; i <= rb; ++i, o += g.pitch) {
+    load_row<T, V>(p, F + o + g.pitch);
+    T ox[V], oy[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const T Fmm = left_of(m, q), Fm0 = m.c[q], Fmp = right_of(m, q);
+      const T F0m = left_of(z, q), F00 = z.c[q], F0p = right_of(z, q);
+      const T Fpm = left_of(p, q), Fp0 = p.c[q], Fpp = right_of(p, q);
+      T mx1 = cxn * (Fpp + Fp0 - F0p - F00);
+      T my1 = cyn * (Fpp - Fp0 + F0p - F00);
+      T mx2 = cxn * (Fp0 + Fpm - F00 - F0m);
+      T my2 = cyn * (Fp0 - Fpm + F00 - F0m);
+      T mx3 = cxn * (F00 + F0m - Fm0 - Fmm);
+      T my3 = cyn * (F00 - F0m + Fm0 - Fmm);
+      T mx4 = cxn * (F0p + F00 - Fmp - Fm0);
+      T my4 = cyn * (F0p - F00 + Fmp - Fm0);
+      T mxsum = (mx1 + mx2 + mx3 + mx4) / (T)4;
+      T mysum = (my1 + my2 + my3 + my4) / (T)4;
+      if (dabs<T>(mxsum) < c.tiny && dabs<T>(mysum) < c.tiny) {
+        ox[q] = mxsum;
+        oy[q] = mysum;
+      } else {
+        T magnitude = dsqrt<T>(mxsum * mxsum + mysum * mysum);
+        ox[q] = mxsum / magnitude;
+        oy[q] = mysum / magnitude;
+      }
+    }
+    store_c<T, V>(mx + o, ox, j0, 1, g.ny);
+    store_c<T, V>(my + o, oy, j0, 1, g.ny);
+    m = z;
+    z = p;
+  }
+}
+
+// 2dvof.py:307-309 get_normal_young loop 2: kappa from mx (i+-1) and my (j+-1)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_kappa(Geom g, Consts<T> c, const T* __restrict__ mx,
+                                                const T* __restrict__ my, T* __restrict__ kappa, int R) {
+  int j0, ra, rb;
+  if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
+  size_t o = at(g, ra, j0);
+  T xm[V], xz[V], xp[V];
+  load_c<T, V>(xm, mx + o - g.pitch);
+  load_c<T, V>(xz, mx + o);
+  for (int i = ra; i <= rb; ++i, o += g.pitch) {
+    load_c<T, V>(xp, mx + o + g.pitch);
+    Row<T, V> y;
+    load_row<T, V>(y, my + o);
+    T k[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      k[q] = -(c.kap_x * (xp[q] - xm[q]) + c.kap_y * (right_of(y, q) - left_of(y, q)));
+    store_c<T, V>(kappa + o, k, j0, 1, g.ny);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      xm[q] = xz[q];
+      xz[q] = xp[q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ predictor
+// 2dvof.py:206-233 advect_upwind: u*, v* from u, v, kappa, F (rho, nu).
+// STORED: read the rho / nu arrays written by cal_nu_rho (verb semantics);
+// otherwise recompute them from F per cell (identical values: rho[i,j] is a
+// pure function of F[i,j] and F is unchanged since cal_nu_rho, 2dvof.py:513-517).
+template <typename T, int V, bool STORED>
+__global__ __launch_bounds__(256) void k_predictor(Geom g, Consts<T> c, const T* __restrict__ u,
+                                                    const T* __restrict__ v, const T* __restrict__ kappa,
+                                                    const T* __restrict__ F, const T* __restrict__ rho,
+                                                    const T* __restrict__ nu, T* __restrict__ us,
+                                                    T* __restrict__ vs, int R) {
+  int j0, ra, rb;
+  if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
+  const T dt = c.dt, dxi = c.dxi, dyi = c.dyi, dxi2 = c.dxi2, dyi2 = c.dyi2;
+  size_t o = at(g, ra, j0);
+  Row<T, V> um, uz, up, vm, vz, vp;
+  T km[V], Fm[V], rm_[V];
+  load_row<T, V>(um, u + o - g.pitch);
+  load_row<T, V>(uz, u + o);
+  load_row<T, V>(vm, v + o - g.pitch);
+  load_row<T, V>(vz, v + o);
+  load_c<T, V>(km, kappa + o - g.pitch);
+  load_c<T, V>(Fm, F + o - g.pitch);
+  if (STORED) load_c<T, V>(rm_, rho + o - g.pitch);
+  for (int i = ra; i <= rb; ++i, o += g.pitch) {
+    load_row<T, V>(up, u + o + g.pitch);
+    load_row<T, V>(vp, v + o + g.pitch);
+    Row<T, V> kz, Fz, rz;
+    T nz[V];
+    load_c<T, V>(kz.c, kappa + o);
+    kz.l = kappa[o - 1];
+    load_c<T, V>(Fz.c, F + o);
+    Fz.l = F[o - 1];
+    if (STORED) {
+      load_c<T, V>(rz.c, rho + o);
+      rz.l = rho[o - 1];
+      load_c<T, V>(nz, nu + o);
+    }
+    T ou[V], ov[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const T u00 = uz.c[q], um0 = um.c[q], up0 = up.c[q], u0m = left_of(uz, q), u0p = right_of(uz, q);
+      const T upm = left_of(up, q);
+      const T v00 = vz.c[q], vm0 = vm.c[q], vp0 = vp.c[q], v0m = left_of(vz, q), v0p = right_of(vz, q);
+      const T vmp = right_of(vm, q);
+      const T F00 = Fz.c[q], Fm0 = Fm[q], F0m = left_of(Fz, q);
+      const T k00 = kz.c[q], km0 = km[q], k0m = left_of(kz, q);
+      T rho00, rhom0, rho0m, nu00;
+      if (STORED) {
+        rho00 = rz.c[q]; rhom0 = rm_[q]; rho0m = left_of(rz, q); nu00 = nz[q];
+      } else {
+        rho00 = rho_of(c, F00); rhom0 = rho_of(c, Fm0); rho0m = rho_of(c, F0m); nu00 = nu_of(c, F00);
+      }
+      {  // :208-220
+        T v_here = (T)0.25 * (vm0 + vmp + v00 + v0p);
+        T dudx = u00 > 0 ? (u00 - um0) * dxi : (up0 - u00) * dxi;
+        T dudy = v_here > 0 ? (u00 - u0m) * dyi : (u0p - u00) * dyi;
+        T kappa_ave = (k00 + km0) / (T)2.0;
+        T fx_kappa = -c.sigma * (F00 - Fm0) * kappa_ave / c.dx;
+        ou[q] = (u00 + dt * (nu00 * (um0 - (T)2 * u00 + up0) * dxi2 + nu00 * (u0m - (T)2 * u00 + u0p) * dyi2 -
+                             u00 * dudx - v_here * dudy + c.gx + fx_kappa * (T)2 / (rho00 + rhom0)));
+      }
+      {  // :221-233
+        T u_here = (T)0.25 * (u0m + u00 + upm + up0);
+        T dvdx = u_here > 0 ? (v00 - vm0) * dxi : (vp0 - v00) * dxi;
+        T dvdy = v00 > 0 ? (v00 - v0m) * dyi : (v0p - v00) * dyi;
+        T kappa_ave = (k00 + k0m) / (T)2.0;
+        T fy_kappa = -c.sigma * (F00 - F0m) * kappa_ave / c.dy;
+        ov[q] = (v00 + dt * (nu00 * (vm0 - (T)2 * v00 + vp0) * dxi2 + nu00 * (v0m - (T)2 * v00 + v0p) * dyi2 -
+                             u_here * dvdx - v00 * dvdy + c.gy + fy_kappa * (T)2 / (rho00 + rho0m)));
+      }
+    }
+    if (i >= 2) store_c<T, V>(us + o, ou, j0, 1, g.ny);  // i in [imin+1, imax]
+    store_c<T, V>(vs + o, ov, j0, 2, g.ny);               // j in [jmin+1, jmax]
+    um = uz; uz = up; vm = vz; vz = vp;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      km[q] = kz.c[q];
+      Fm[q] = Fz.c[q];
+      if (STORED) rm_[q] = rz.c[q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ rhs
+// 2dvof.py:239-241, hoisted out of the Jacobi loop (it does not depend on p;
+// precedent: cal_velocity_div, diff_vof_replaced.py:277-282).
+template <typename T, int V, bool STORED>
+__global__ __launch_bounds__(256) void k_rhs(Geom g, Consts<T> c, const T* __restrict__ us,
+                                              const T* __restrict__ vs, const T* __restrict__ F,
+                                              const T* __restrict__ rho, T* __restrict__ rhs, int R) {
+  int j0, ra, rb;
+  if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
+  size_t o = at(g, ra, j0);
+  T uz[V], up[V];
+  load_c<T, V>(uz, us + o);
+  for (int i = ra; i <= rb; ++i, o += g.pitch) {
+    load_c<T, V>(up, us + o + g.pitch);
+    Row<T, V> vz;
+    load_c<T, V>(vz.c, vs + o);
+    vz.r = vs[o + V];
+    T f[V], out[V];
+    load_c<T, V>(f, STORED ? rho + o : F + o);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      T r = STORED ? f[q] : rho_of(c, f[q]);
+      out[q] = r / c.dt * ((up[q] - uz[q]) * c.dxi + (right_of(vz, q) - vz.c[q]) * c.dyi);
+    }
+    store_c<T, V>(rhs + o, out, j0, 1, g.ny);
+#pragma unroll
+    for (int q = 0; q < V; ++q) uz[q] = up[q];
+  }
+}
+
+// ------------------------------------------------------------------ Jacobi
+// 2dvof.py:258-266: one sweep p -> pn (ping-pong replaces the copy-back loop).
+// North-star kernel: 3 arrays * sizeof(T) per cell of HBM traffic.  D rows of
+// p and rhs are prefetched into registers ahead of use.  RESID additionally
+// reduces max|pn - p| over owned rows (wave shuffle -> one atomic per wave);
+// not part of the reference (extension).
+template <typename T, int V, int D, bool RESID>
+__global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __restrict__ p,
+                                                 const T* __restrict__ rhs, T* __restrict__ pn, int R,
+                                                 unsigned long long* __restrict__ resid_bits) {
+  int j0, ra, rb;
+  if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
+  const int nx = g.nx, ny = g.ny;
+  T an[V], as_[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    an[q] = (j0 + q) != ny ? c.dyi2 : (T)0.0;
+    as_[q] = (j0 + q) != 1 ? c.dyi2 : (T)0.0;
+  }
+  const int64_t pitch = g.pitch;
+  size_t o = at(g, ra, j0);
+  T w[V];
+  Row<T, V> cur;
+  load_c<T, V>(w, p + o - pitch);
+  load_row<T, V>(cur, p + o);
+  Row<T, V> qe[D];  // rows i+1 .. i+D of p
+  T qb[D][V];       // rows i .. i+D-1 of rhs
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (ra + d <= rb) {
+      load_row<T, V>(qe[d], p + o + (int64_t)(d + 1) * pitch);
+      load_c<T, V>(qb[d], rhs + o + (int64_t)d * pitch);
+    }
+  }
+  T res = (T)0;
+  for (int i0 = ra; i0 <= rb; i0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int i = i0 + d;
+      if (i > rb) break;
+      Row<T, V> e = qe[d];
+      T b[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) b[q] = qb[d][q];
+      if (i + D <= rb) {  // refill this slot with the rows D ahead
+        load_row<T, V>(qe[d], p + o + (int64_t)(D + 1) * pitch);
+        load_c<T, V>(qb[d], rhs + o + (int64_t)D * pitch);
+      }
+      const T ae = i != nx ? c.dxi2 : (T)0.0;
+      const T aw = i != 1 ? c.dxi2 : (T)0.0;
+      T out[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const T ap = (T)-1.0 * (ae + aw + an[q] + as_[q]);
+        out[q] = (b[q] - ae * e.c[q] - aw * w[q] - an[q] * right_of(cur, q) - as_[q] * left_of(cur, q)) / ap;
+        if (RESID) {
+          if (i >= g.own_lo && i <= g.own_hi && j0 + q <= ny) res = vmax(res, dabs<T>(out[q] - cur.c[q]));
+        }
+      }
+      store_c<T, V>(pn + o, out, j0, 1, ny);
+#pragma unroll
+      for (int q = 0; q < V; ++q) w[q] = cur.c[q];
+      cur = e;
+      o += pitch;
+    }
+  }
+  if (RESID) {
+    double r = (double)res;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) r = vmax(r, __shfl_down(r, s, 64));
+    if ((threadIdx.x & 63) == 0 && r > 0.0) atomicMax(resid_bits, (unsigned long long)__double_as_longlong(r));
+  }
+}
+
+// ------------------------------------------------------------------ corrector
+// 2dvof.py:269-280 update_uv (+ Courant prints -> counter over owned rows)
+template <typename T, int V, bool STORED>
+__global__ __launch_bounds__(256) void k_correct(Geom g, Consts<T> c, const T* __restrict__ p,
+                                                  const T* __restrict__ F, const T* __restrict__ rho,
+                                                  const T* __restrict__ us, const T* __restrict__ vs,
+                                                  T* __restrict__ u, T* __restrict__ v, int R,
+                                                  unsigned long long* __restrict__ courant) {
+  int j0, ra, rb;
+  if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
+  size_t o = at(g, ra, j0);
+  T pm[V], rm_[V];
+  load_c<T, V>(pm, p + o - g.pitch);
+  {
+    T f[V];
+    load_c<T, V>(f, STORED ? rho + o - g.pitch : F + o - g.pitch);
+#pragma unroll
+    for (int q = 0; q < V; ++q) rm_[q] = STORED ? f[q] : rho_of(c, f[q]);
+  }
+  unsigned int viol = 0;
+  for (int i = ra; i <= rb; ++i, o += g.pitch) {
+    Row<T, V> pz, rz;
+    load_c<T, V>(pz.c, p + o);
+    pz.l = p[o - 1];
+    {
+      T f[V];
+      load_c<T, V>(f, STORED ? rho + o : F + o);
+      T fl = STORED ? rho[o - 1] : F[o - 1];
+#pragma unroll
+      for (int q = 0; q < V; ++q) rz.c[q] = STORED ? f[q] : rho_of(c, f[q]);
+      rz.l = STORED ? fl : rho_of(c, fl);
+    }
+    T usz[V], vsz[V], ou[V], ov[V];
+    load_c<T, V>(usz, us + o);
+    load_c<T, V>(vsz, vs + o);
+    const bool own = i >= g.own_lo && i <= g.own_hi;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      T r = (rz.c[q] + rm_[q]) * (T)0.5;
+      ou[q] = usz[q] - c.dt / r * (pz.c[q] - pm[q]) * c.dxi;
+      T r2 = (rz.c[q] + left_of(rz, q)) * (T)0.5;
+      ov[q] = vsz[q] - c.dt / r2 * (pz.c[q] - left_of(pz, q)) * c.dyi;
+      const int j = j0 + q;
+      if (own && j <= g.ny) {
+        if (i >= 2 && ou[q] * c.dt > c.cfl_x) viol++;
+        if (j >= 2 && ov[q] * c.dt > c.cfl_y) viol++;
+      }
+    }
+    if (i >= 2) store_c<T, V>(u + o, ou, j0, 1, g.ny);
+    store_c<T, V>(v + o, ov, j0, 2, g.ny);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      pm[q] = pz.c[q];
+      rm_[q] = rz.c[q];
+    }
+  }
+  if (__any(viol != 0)) {
+    unsigned int tot = viol;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) tot += __shfl_down(tot, s, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(courant, (unsigned long long)tot);
+  }
+}
+
+// ------------------------------------------------------------------ FCT
+// Shared per-face / per-cell arithmetic of fct_x_sweep / fct_y_sweep.
+// Face f between cells f-1 and f carries velocity w:  (2dvof.py:325-326, 342-343; S4)
+//   L(f) = (w*dt) * (w >= 0 ? F[f-1] : F[f])     low-order (donor) flux
+//   H(f) = (w*dt) * (w <= 0 ? F[f-1] : F[f])     high-order (downwind) flux
+//   a(f) = H(f) - L(f)                           anti-diffusive flux (ax / ay)
+template <typename T>
+__device__ __forceinline__ void fct_face(T w, T dt, T Fm, T Fp, T& L, T& a) {
+  const T wd = w * dt;
+  L = w >= 0 ? wd * Fm : wd * Fp;
+  const T H = w <= 0 ? wd * Fm : wd * Fp;
+  a = H - L;
+}
+// stage A (:324-331 / :388-395): Ftd from F, the low-order fluxes through the
+// cell's lower (Llo) and upper (Lhi) face, and dv.
+//   x-sweep: flux = fl_L - fr_L + 0 - 0 ; y-sweep: flux = 0 - 0 + fb_L - ft_L  (same value: Llo - Lhi)
+template <typename T>
+__device__ __forceinline__ T fct_ftd(const Consts<T>& c, T F, T Llo, T Lhi, T dv) {
+  T ftd = (F + (Llo - Lhi) * c.dy / c.dxdy) * c.dx * c.dy / dv;
+  if (ftd > (T)1. || ftd < 0) ftd = var3((T)0, (T)1, ftd);
+  return ftd;
+}
+// stage B limiter ratios (:351-363 / :417-429); alo / ahi = anti-diffusive flux
+// through the cell's lower / upper face; the other direction's terms are exact zeros.
+template <typename T>
+__device__ __forceinline__ void fct_ratios(const Consts<T>& c, T ftd, T ftd_m, T ftd_p, T alo, T ahi, T& rp, T& rm) {
+  const T Z = (T)0;
+  T fmax = vmax(vmax(ftd, ftd_m), ftd_p);
+  T fmin = vmin(vmin(ftd, ftd_m), ftd_p);
+  T pp = vmax(Z, alo) - vmin(Z, ahi);
+  T qp = (fmax - ftd) * c.dx;  // dx in both sweeps (:417)
+  rp = pp > 0 ? vmin((T)1, qp / pp) : (T)0.0;
+  T pm = vmax(Z, ahi) - vmin(Z, alo);
+  T qm = (ftd - fmin) * c.dx;
+  rm = pm > 0 ? vmin((T)1, qm / pm) : (T)0.0;
+}
+// stage C (:365-374 / :431-440): limiter of face f between cells f-1 (m) and f (p)
+template <typename T>
+__device__ __forceinline__ T fct_climit(T a, T rp_m, T rm_m, T rp_p, T rm_p) {
+  return a >= 0 ? vmin(rp_p, rm_m) : vmin(rp_m, rm_p);
+}
+// stage D (:376-382 / :442-448) + optional fused post_process_f (:452-455)
+template <typename T, bool POST>
+__device__ __forceinline__ T fct_final(const Consts<T>& c, T ftd, T alo, T clo, T ahi, T chi, T dv) {
+  T f = ftd - ((ahi * chi - alo * clo) / (c.dy)) * c.dx * c.dy / dv;
+  f = var3((T)0, (T)1, f);
+  if (POST) f = var3(f, (T)0, (T)1);
+  return f;
+}
+
+// 2dvof.py:321-382 fct_x_sweep, the four barrier-separated loops fused into
+// one pass: each lane marches along i (the sweep direction) with a 3-row-deep
+// software pipeline (face -> Ftd -> rp/rm -> cx -> F').  Out of place: reads
+// F, writes Fn (the twin); the host swaps the two pointers afterwards.
+// Zero-ghost semantics (S5): Ftd, rp, rm outside [ilo, ihi] and cx at face
+// ilo read as 0, exactly what the never-written ghost entries hold.
+template <typename T, int V, bool POST>
+__global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __restrict__ F,
+                                                const T* __restrict__ u, T* __restrict__ Fn, int R) {
+  int j0, ra, rb;
+  if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
+  const int ilo = g.ilo, ihi = g.ihi;
+  // state, indexed relative to the newest row r
+  T F1[V];                       // F[r-1]
+  T u1[V];                       // u[r-1]
+  T L1[V];                       // L(r-1)
+  T a1[V], a2[V], a3[V];         // a(r-1), a(r-2), a(r-3)
+  T t2[V], t3[V];                // Ftd[r-2], Ftd[r-3]  (Ftd[r-1] is produced in iteration r)
+  T d2[V], d3[V];                // dv[r-2], dv[r-3]
+  T rp3[V], rm3[V];              // rp/rm[r-3]
+  T c3[V];                       // cx(face r-3)
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    u1[q] = L1[q] = a1[q] = a2[q] = a3[q] = t2[q] = t3[q] = rp3[q] = rm3[q] = c3[q] = (T)0;
+    d2[q] = d3[q] = (T)1;
+  }
+  auto rowptr = [&](const T* base, int r) {
+    int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
+    return base + at(g, rc, j0);
+  };
+  load_c<T, V>(F1, rowptr(F, ra - 3));
+  for (int r = ra - 2; r <= rb + 3; ++r) {
+    T Fr[V], ur[V];
+    load_c<T, V>(Fr, rowptr(F, r));
+    load_c<T, V>(ur, rowptr(u, r));
+    T out[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      // S1: face r
+      T Lr, ar;
+      fct_face<T>(ur[q], c.dt, F1[q], Fr[q], Lr, ar);
+      // S2: Ftd[r-1], dv[r-1]
+      const int i1 = r - 1;
+      T dv1 = c.dxdy - c.dtdy * (ur[q] - u1[q]);
+      T tn = (i1 >= ilo && i1 <= ihi) ? fct_ftd<T>(c, F1[q], L1[q], Lr, dv1) : (T)0;
+      // S3: rp/rm[r-2]
+      const int i2 = r - 2;
+      T rp2 = (T)0, rm2 = (T)0;
+      if (i2 >= ilo && i2 <= ihi) fct_ratios<T>(c, t2[q], t3[q], tn, a2[q], a1[q], rp2, rm2);
+      // S4: cx(face r-2) between cells r-3 and r-2
+      T c2 = (i2 > ilo && i2 <= ihi + 1) ? fct_climit<T>(a2[q], rp3[q], rm3[q], rp2, rm2) : (T)0;
+      // S5: F'[r-3]
+      out[q] = fct_final<T, POST>(c, t3[q], a3[q], c3[q], a2[q], c2, d3[q]);
+      // shift the pipeline
+      F1[q] = Fr[q]; u1[q] = ur[q]; L1[q] = Lr;
+      a3[q] = a2[q]; a2[q] = a1[q]; a1[q] = ar;
+      t3[q] = t2[q]; t2[q] = tn;
+      d3[q] = d2[q]; d2[q] = dv1;
+      rp3[q] = rp2; rm3[q] = rm2; c3[q] = c2;
+    }
+    const int io = r - 3;
+    if (io >= ra && io <= rb) store_c<T, V>(Fn + at(g, io, j0), out, j0, 1, g.ny);
+  }
+}
+// 2dvof.py:385-448 fct_y_sweep, fused like k_fct_x.  The sweep direction is
+// the contiguous one, so the +-3-cell dependency is resolved across lanes with
+// wave shuffles: a wave owns 64*V consecutive cells of one row, of which the
+// inner 64*V - 8 are valid outputs (tiles overlap by 8 columns; 4 keeps the
+// 16-byte alignment of the lane accesses).  Rows are independent.
+template <typename T, int V, bool POST>
+__global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __restrict__ F,
+                                                const T* __restrict__ v, T* __restrict__ Fn, int R, int nty) {
+  constexpr int W = 64 * V, STRIDE = W - 8;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int tj = wave % nty, ch = wave / nty;
+  const int c0 = -3 + tj * STRIDE;
+  const int j0 = c0 + lane * V;
+  const int ra = g.ilo + ch * R;
+  if (ra > g.ihi) return;  // wave-uniform
+  const int rb = ra + R - 1 < g.ihi ? ra + R - 1 : g.ihi;
+  const int ny = g.ny;
+  const int jlo = c0 + 4 > 1 ? c0 + 4 : 1;
+  const int jhi = c0 + W - 5 < ny ? c0 + W - 5 : ny;
+  size_t o = at(g, ra, j0);
+  for (int i = ra; i <= rb; ++i, o += g.pitch) {
+    T Fz[V], vz[V];
+    load_c<T, V>(Fz, F + o);
+    load_c<T, V>(vz, v + o);
+    const T Fl = __shfl_up(Fz[V - 1], 1, 64);
+    T L[V], a[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) fct_face<T>(vz[q], c.dt, q == 0 ? Fl : Fz[q - 1], Fz[q], L[q], a[q]);
+    const T Ln = __shfl_down(L[0], 1, 64), an_ = __shfl_down(a[0], 1, 64), vn = __shfl_down(vz[0], 1, 64);
+    T td[V], dv[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const int j = j0 + q;
+      dv[q] = c.dxdy - c.dtdx * ((q == V - 1 ? vn : vz[q + 1]) - vz[q]);
+      td[q] = (j >= 1 && j <= ny) ? fct_ftd<T>(c, Fz[q], L[q], q == V - 1 ? Ln : L[q + 1], dv[q]) : (T)0;
+    }
+    const T tl = __shfl_up(td[V - 1], 1, 64), tr = __shfl_down(td[0], 1, 64);
+    T rp[V], rm[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const int j = j0 + q;
+      rp[q] = rm[q] = (T)0;
+      if (j >= 1 && j <= ny)
+        fct_ratios<T>(c, td[q], q == 0 ? tl : td[q - 1], q == V - 1 ? tr : td[q + 1], a[q],
+                      q == V - 1 ? an_ : a[q + 1], rp[q], rm[q]);
+    }
+    const T rpl = __shfl_up(rp[V - 1], 1, 64), rml = __shfl_up(rm[V - 1], 1, 64);
+    T cy[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const int j = j0 + q;  // face j between cells j-1 and j; written for j in [2, ny+1]
+      cy[q] = (j >= 2 && j <= ny + 1)
+                  ? fct_climit<T>(a[q], q == 0 ? rpl : rp[q - 1], q == 0 ? rml : rm[q - 1], rp[q], rm[q])
+                  : (T)0;
+    }
+    const T cn = __shfl_down(cy[0], 1, 64);
+    T out[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      out[q] = fct_final<T, POST>(c, td[q], a[q], cy[q], q == V - 1 ? an_ : a[q + 1], q == V - 1 ? cn : cy[q + 1],
+                                  dv[q]);
+    store_c<T, V>(Fn + o, out, j0, jlo, jhi);
+  }
+}
+
+}  // namespace vof

@@ -1,0 +1,34 @@
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "taichi-2d-vof_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libvof_oracle.so")
+
+
+@pytest.fixture(scope="session")
+def oracle_api():
+    """The CPU oracle (test infrastructure) bound through the same ctypes prototypes."""
+    from vof2d import _abi
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(ORACLE_SO)
+    return _abi.bind(lib, "ovof_", optional=("timer_start", "timer_stop", "time_jacobi"))
+
+
+@pytest.fixture(scope="session")
+def hip_api():
+    from vof2d._lib import hip_api as load
+    return load()
