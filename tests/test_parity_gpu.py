@@ -1,0 +1,209 @@
+"""GPU parity: the HIP library (through the C ABI) against the CPU oracle on the same inputs.
+Bar: value-for-value equality (IEEE ==) in fp64 and fp32 -- both sides evaluate the reference's
+expressions in the same order with FMA contraction off, so no tolerance is needed."""
+import numpy as np
+import pytest
+
+from util import STATE, assert_fields_same, engine, same, diff_report
+from vof2d import halo_rows, VOF_FLAG_NO_GRAPH
+
+pytestmark = pytest.mark.gpu
+
+SCRATCH = ("u_star", "v_star", "mx", "my", "kappa", "rhs")
+PARAMS = ("sigma", "dt", "dx", "dy", "dxi", "dyi", "dxi2", "dyi2", "rho_l", "rho_g", "nu_l", "nu_g", "gx", "gy",
+          "nrm_x", "nrm_y", "kap_x", "kap_y", "dxdy", "dtdy", "dtdx", "cfl_x", "cfl_y", "half_dx", "half_dy",
+          "sqrt2dx", "tiny", "Lx", "Ly")
+
+
+@pytest.mark.parametrize("nx,ny,dtype,cast", [(128, 128, "f64", "f32"), (200, 200, "f32", "f32"),
+                                              (4096, 4096, "f64", "f32"), (100, 37, "f64", "none")])
+def test_constants(hip_api, oracle_api, nx, ny, dtype, cast):
+    if nx > 1024:  # constants only; do not allocate a big oracle grid
+        import vof_oracle_np as onp
+        p = onp.Params(nx, ny, coord_cast=cast)
+        e = engine(hip_api, nx, ny, dtype, cast)
+        assert e.get_param("dx") == p.dx_d and e.get_param("dxi2") == p.dxi_d ** 2
+        return
+    a, b = engine(hip_api, nx, ny, dtype, cast), engine(oracle_api, nx, ny, dtype, cast)
+    for k in PARAMS:
+        assert a.get_param(k) == b.get_param(k), k
+
+
+@pytest.mark.parametrize("dtype,cast", [("f64", "f32"), ("f64", "none"), ("f32", "f32")])
+@pytest.mark.parametrize("ic", [1, 2, 3])
+@pytest.mark.parametrize("nx,ny", [(32, 32), (33, 17), (128, 128), (7, 261), (200, 200)])
+def test_set_init_F(hip_api, oracle_api, nx, ny, ic, dtype, cast):
+    a, b = engine(hip_api, nx, ny, dtype, cast, ic=ic), engine(oracle_api, nx, ny, dtype, cast, ic=ic)
+    assert_fields_same(a, b, ("F",), ctx="init ic=%d" % ic)
+
+
+STEP_CASES = [
+    # nx, ny, ic, dtype, cast, checkpoints
+    (32, 32, 1, "f64", "f32", (1, 2, 3, 10, 100)),
+    (33, 17, 2, "f64", "f32", (1, 2, 10, 60)),
+    (24, 40, 3, "f64", "none", (1, 2, 10, 60)),
+    (7, 261, 1, "f64", "f32", (1, 2, 11)),        # ragged: fewer rows than a wave chunk, 3 column tiles
+    (130, 129, 2, "f64", "f32", (1, 2, 25)),      # odd ny: last lane pair straddles the ghost column
+    (3, 3, 1, "f64", "f32", (1, 2, 5)),           # minimum size
+    (256, 384, 3, "f64", "f32", (1, 2, 20)),
+    (200, 200, 1, "f32", "f32", (1, 2, 10, 100)), # the reference as shipped (2dvof.py:9,19-20)
+    (48, 48, 2, "f32", "f32", (1, 10, 100)),
+    (65, 258, 3, "f32", "none", (1, 2, 12)),
+]
+
+
+@pytest.mark.parametrize("nx,ny,ic,dtype,cast,steps", STEP_CASES)
+def test_fused_step_matches_oracle(hip_api, oracle_api, nx, ny, ic, dtype, cast, steps):
+    a, b = engine(hip_api, nx, ny, dtype, cast, ic=ic), engine(oracle_api, nx, ny, dtype, cast, ic=ic)
+    done = 0
+    for st in steps:
+        a.step(st - done)
+        b.step(st - done)
+        done = st
+        assert a.istep == b.istep == st
+        assert_fields_same(a, b, STATE + SCRATCH, ctx="%dx%d ic%d %s step %d" % (nx, ny, ic, dtype, st))
+        assert a.get_counter("courant_violations") == b.get_counter("courant_violations")
+
+
+VERBS = ("cal_nu_rho", "get_normal_young", "advect_upwind", "set_BC", "solve_p_jacobi", "update_uv", "set_BC",
+         "solve_VOF_rudman", "post_process_f", "set_BC")
+
+
+@pytest.mark.parametrize("nx,ny,ic,dtype", [(40, 56, 1, "f64"), (33, 130, 2, "f64"), (64, 64, 3, "f32")])
+def test_each_verb_matches_oracle(hip_api, oracle_api, nx, ny, ic, dtype):
+    """Kernel-boundary parity: drive both sides through the literal main loop (2dvof.py:506-528)
+    one verb at a time and compare every observable field after every verb."""
+    a, b = engine(hip_api, nx, ny, dtype, "f32", ic=ic), engine(oracle_api, nx, ny, dtype, "f32", ic=ic)
+    names = STATE + ("u_star", "v_star", "mx", "my", "kappa", "rho", "nu")
+    for istep in range(1, 8):
+        for verb in VERBS:
+            for e in (a, b):
+                if verb == "solve_p_jacobi":
+                    e.solve_p_jacobi(10 if istep % 2 else 3)   # even and odd sweep counts
+                elif verb == "solve_VOF_rudman":
+                    e.solve_VOF_rudman(istep)
+                else:
+                    getattr(e, verb)()
+            assert_fields_same(a, b, names, ctx="istep %d after %s" % (istep, verb))
+
+
+def test_single_sweeps_and_field_io(hip_api, oracle_api):
+    """fct_x_sweep / fct_y_sweep alone on a perturbed state set through set_field (from_numpy)."""
+    nx, ny = 48, 70
+    rng = np.random.default_rng(7)
+    a, b = engine(hip_api, nx, ny, "f64", "f32", ic=2), engine(oracle_api, nx, ny, "f64", "f32", ic=2)
+    u = 0.05 * rng.standard_normal((nx + 2, ny + 2))
+    v = 0.05 * rng.standard_normal((nx + 2, ny + 2))
+    F = np.clip(b.get("F") + 0.2 * rng.standard_normal((nx + 2, ny + 2)), 0, 1)
+    for e in (a, b):
+        e.set("u", u); e.set("v", v); e.set("F", F)
+        e.set_BC()
+    assert_fields_same(a, b, STATE, ctx="after set_field + set_BC")
+    for k in range(6):
+        for e in (a, b):
+            (e.fct_x_sweep if k % 2 == 0 else e.fct_y_sweep)()
+        assert_fields_same(a, b, ("F",), ctx="sweep %d" % k)
+    for e in (a, b):
+        e.post_process_f()
+    assert_fields_same(a, b, ("F",), ctx="post_process_f")
+    # rows sub-range I/O
+    assert same(a.get("F", (3, 9)), b.get("F", (3, 9)))
+
+
+def test_graph_replay_equals_eager(hip_api):
+    a = engine(hip_api, 96, 80, "f64", "f32", ic=3)
+    b = engine(hip_api, 96, 80, "f64", "f32", ic=3, flags=VOF_FLAG_NO_GRAPH)
+    a.step(25); b.step(25)
+    assert_fields_same(a, b, STATE, ctx="graph vs eager")
+
+
+def test_sigma_is_a_runtime_scalar(hip_api, oracle_api):
+    a, b = engine(hip_api, 40, 40, "f64", "f32", ic=2), engine(oracle_api, 40, 40, "f64", "f32", ic=2)
+    for e in (a, b):
+        e.step(3)
+        e.set_param("sigma", 0.05)
+        e.step(5)
+    assert a.get_param("sigma") == 0.05
+    assert_fields_same(a, b, STATE, ctx="after sigma change")
+
+
+def test_error_paths(hip_api):
+    from vof2d.engine import VofError
+    e = engine(hip_api, 16, 16, "f64", "f32", ic=1)
+    with pytest.raises(VofError):
+        e.set_init_F(4)
+    with pytest.raises(VofError):
+        e.get("no_such_field")
+    with pytest.raises(ValueError):
+        e.set("F", np.zeros((3, 3)))
+    with pytest.raises(VofError):
+        e.get("F", rows=(0, 40))
+    with pytest.raises(VofError):
+        e.set_param("dt", 1.0)
+
+
+def test_residual_extension(hip_api, oracle_api):
+    a, b = engine(hip_api, 64, 48, "f64", "f32", ic=1), engine(oracle_api, 64, 48, "f64", "f32", ic=1)
+    for e in (a, b):
+        e.step(4)
+        e.cal_nu_rho(); e.get_normal_young(); e.advect_upwind(); e.set_BC()
+    ra = a.jacobi_sweeps_residual(10)
+    rb = b.jacobi_sweeps_residual(10)
+    assert ra == rb and ra > 0
+    assert_fields_same(a, b, ("p",), ctx="after 10 residual sweeps")
+    ita, resa = a.solve_p_residual(1e-3 * ra, 400, 20)
+    itb, resb = b.solve_p_residual(1e-3 * ra, 400, 20)
+    assert (ita, resa) == (itb, resb)
+    assert_fields_same(a, b, ("p",), ctx="after residual-terminated solve")
+
+
+@pytest.mark.parametrize("nstrips", [2, 3])
+def test_strip_decomposition_on_one_gpu(hip_api, nstrips):
+    """N strips on one device with VOF_HALO_ROWS deep halos exchanged once per step (device copies
+    stand in for RCCL send/recv) reproduce the single-domain run exactly on the owned rows."""
+    nx, ny, W = 120, 70, halo_rows(10)
+    full = engine(hip_api, nx, ny, "f64", "f32", ic=1)
+    bounds = [round(k * nx / nstrips) for k in range(nstrips + 1)]
+    strips = []
+    for k in range(nstrips):
+        lo, hi = bounds[k] + 1, bounds[k + 1]
+        strips.append(engine(hip_api, nx, ny, "f64", "f32", ic=1, rows=(max(0, lo - W), min(nx + 1, hi + W)),
+                             own=(lo, hi)))
+    for step in range(1, 31):
+        full.step(1)
+        for s in strips:
+            s.step(1)
+        for k in range(nstrips - 1):
+            lo_s, hi_s = strips[k], strips[k + 1]
+            edge = lo_s.own_hi
+            for f in STATE:
+                lo_s.copy_rows_from(hi_s, f, edge + 1, edge + W)
+                hi_s.copy_rows_from(lo_s, f, edge + 1 - W, edge)
+        for s in strips:
+            g0 = 0 if s.own_lo == 1 else s.own_lo
+            g1 = nx + 1 if s.own_hi == nx else s.own_hi
+            assert_fields_same(s, full, STATE, rows=(g0, g1), ctx="step %d strip %d..%d" % (step, s.own_lo, s.own_hi))
+    assert sum(s.get_counter("courant_violations") for s in strips) == full.get_counter("courant_violations")
+
+
+def test_baseline_size_4096_matches_oracle_and_properties(hip_api, oracle_api):
+    """BASELINE configs[2] size (4096^2 fp64 dam-break): two steps value-for-value against the
+    oracle, then size-independent properties after more steps."""
+    n = 4096
+    a = engine(hip_api, n, n, "f64", "f32", ic=1)
+    b = engine(oracle_api, n, n, "f64", "f32", ic=1)
+    m0 = float(a.get("F")[1:-1, 1:-1].sum())
+    a.step(2); b.step(2)
+    for f in STATE:
+        x, y = a.get(f), b.get(f)
+        assert same(x, y), diff_report(x, y, f)
+    del b
+    a.step(18)
+    F = a.get("F")
+    assert F.min() >= 0.0 and F.max() <= 1.0
+    assert abs(float(F[1:-1, 1:-1].sum()) - m0) < 1e-6 * m0
+    assert a.get_counter("courant_violations") == 0
+    # set_BC postconditions (2dvof.py:162-189)
+    assert same(F[:, 0], F[:, 1]) and same(F[0, :], F[1, :]) and same(F[n + 1, :], F[n, :])
+    u, v = a.get("u"), a.get("v")
+    assert not u[1].any() and not u[n + 1].any() and not v[:, 1].any() and not v[:, n + 1].any()
