@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-updates/s of the fused VOF time step + HBM GB/s of the Jacobi sweep.
+
+    python bench.py --gpus 1 --steps K --warmup W              (4096^2 fp64 dam-break)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+                                                             (8192^2 fp64, N row strips, strong)
+
+A "step" is one pass of the solver part of 2dvof.py's main loop (:506-528): normals + curvature,
+momentum predictor, set_BC, rhs, 10 Jacobi sweeps, velocity correction, set_BC, the two FCT
+sweeps (+post_process_f), set_BC -- and, for N > 1, the per-step halo exchange.  Inputs are
+generated on the device by set_init_F (-ic 1), so they are resident in HBM when timing starts.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "measurement" for every field).
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "taichi-2d-vof_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nx", type=int, default=0, help="grid size (default 4096 at 1 GPU, 8192 at N > 1)")
+    ap.add_argument("--ny", type=int, default=0)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("-ic", type=int, default=1, choices=[1, 2, 3])
+    ap.add_argument("--jacobi-sweeps-timed", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def load_pmc_traffic(nx, ny, dtype):
+    """HBM bytes per Jacobi launch from the committed rocprofv3 --pmc passes (profiles/), if the
+    profile was taken at this workload; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "jacobi_pmc.json")
+    try:
+        rec = json.load(open(path))
+        if (rec["nx"], rec["ny"], rec["dtype"]) == (nx, ny, dtype):
+            return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(nx, ny, dtype, ic, target_s):
+    """The CPU oracle (scalar-C restatement, OpenMP over i, -O2 -ffp-contract=off = the parity
+    build) timed on this host's cores on a bounded sample of the same workload."""
+    from vof2d import _abi
+    from vof2d.engine import Engine, make_desc
+    so = os.path.join(ROOT, "oracle", "_build", "libvof_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    api = _abi.bind(ctypes.CDLL(so), "ovof_", optional=("timer_start", "timer_stop", "time_jacobi"))
+    cores = len(os.sched_getaffinity(0))
+    e = Engine(api, make_desc(api, nx, ny, dtype, "f32"))
+    e.set_init_F(ic)
+    t0 = time.perf_counter()
+    e.step(1)
+    t1 = time.perf_counter() - t0
+    n = max(1, min(200, int(target_s / max(t1, 1e-6)) - 1))
+    t0 = time.perf_counter()
+    e.step(n)
+    dt = time.perf_counter() - t0
+    e.close()
+    return {"value": nx * ny * n / dt, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d %s dam-break, %d steps after 1 warm-up step, oracle/vof_oracle.c "
+                      "(-O2 -ffp-contract=off, OpenMP %d threads), %.1f s" % (nx, ny, dtype, n, cores, dt),
+            "ms_per_step": 1e3 * dt / n}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    nx = a.nx or (4096 if world == 1 else 8192)
+    ny = a.ny or nx
+    esz = 8 if a.dtype == "f64" else 4
+
+    if world == 1:
+        # single GPU: no torch in the process at all -- ctypes -> C ABI -> HIP
+        from vof2d._lib import hip_api
+        from vof2d.engine import Engine, make_desc
+        api = hip_api()
+        eng = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=local))
+        eng.set_init_F(a.ic)
+        eng.step(a.warmup)
+        eng.sync()
+        t0 = time.perf_counter()
+        eng.step(a.steps)
+        eng.sync()
+        elapsed = time.perf_counter() - t0
+        solver = None
+    else:
+        import torch
+        import torch.distributed as dist
+        from vof2d.strips import StripSolver
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local)
+        eng = solver.eng
+        solver.step(a.warmup)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver.step(a.steps)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: Jacobi sweep, timed with HIP events on the stream it is launched on
+    own_rows = eng.own_hi - eng.own_lo + 1
+    comp_rows = min(nx, eng.row_hi - 1) - max(1, eng.row_lo + 1) + 1
+    ms_sweep = eng.time_jacobi(a.jacobi_sweeps_timed)
+    algo_bytes = 3 * esz * comp_rows * ny          # read p, read rhs, write p' per computed cell
+    achieved = algo_bytes / (ms_sweep * 1e-3) / 1e9
+    violations = eng.get_counter("courant_violations")
+
+    if rank == 0:
+        out = {
+            "metric": "cell-updates/sec (whole node), %dx%d %s dam-break" % (nx, ny, "fp64" if esz == 8 else "fp32"),
+            "value": nx * ny * a.steps / elapsed,
+            "unit": "cell-updates/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": a.dtype,
+            "data": "synthetic (set_init_F -ic %d generated on device)" % a.ic,
+            "config": {"workload": "%dx%d -ic %d %s, 10 Jacobi sweeps/step, %s" % (
+                nx, ny, a.ic, a.dtype, "single strip" if world == 1 else
+                "%d row strips, %d-row deep halo, 1 RCCL P2P exchange/step" % (world, solver.halo)),
+                "nx": nx, "ny": ny, "jacobi_iters": 10,
+                "bytes_per_cell_update_algorithmic": 58 * esz},
+            "roofline": {"bound": "hbm", "kernel": "k_jacobi", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": load_pmc_traffic(nx, ny, a.dtype) if world == 1 else None,
+                         "us_per_launch": 1e3 * ms_sweep, "algorithmic_bytes_per_launch": algo_bytes,
+                         "launches_timed": a.jacobi_sweeps_timed},
+            "step_hbm_gbs_algorithmic": 58 * esz * nx * ny * a.steps / elapsed / 1e9,
+            "courant_violations": violations,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nx, ny, a.dtype, a.ic, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        solver.close()
+        dist.destroy_process_group()
+    else:
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()

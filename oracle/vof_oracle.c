@@ -163,8 +163,10 @@ int ovof_solve_p_jacobi(vof2d_handle h, int32_t n) {
 }
 /* Extension: n sweeps, *residual = max|p_new - p| over owned rows of the last one. */
 int ovof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual) {
-  (void)build_rhs; /* the oracle recomputes the (iteration-invariant) rhs in every sweep, like :239-241 */
   if (!h || !residual || n < 1) return VOF_EINVAL;
+  /* the extension defines rhs on the CURRENT F (rho = f(F)); the sweeps below recompute the
+   * iteration-invariant rhs from the rho array every time, like :239-241 */
+  if (build_rhs) ovof_cal_nu_rho(h);
   for (int k = 0; k < n; ++k) DISPATCH(h, solve_p_jacobi, k == n - 1 ? residual : NULL);
   return VOF_OK;
 }
@@ -175,7 +177,7 @@ int ovof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t
   double r = 0.0;
   while (done < max_iters) {
     int n = check_every < max_iters - done ? check_every : max_iters - done;
-    ovof_jacobi_sweeps_residual(h, n, 1, &r);
+    ovof_jacobi_sweeps_residual(h, n, done == 0, &r);
     done += n;
     if (r <= tol) break;
   }

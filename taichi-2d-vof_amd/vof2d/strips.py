@@ -1,0 +1,199 @@
+"""Row-strip domain decomposition: one process per GPU, halo exchange over RCCL.
+
+The grid is cut along the slow index i (x) into contiguous strips.
+Each rank stores its owned rows plus W = VOF_HALO_ROWS(jacobi_iters) halo rows
+per interior side and runs the *whole* fused step on the extended strip; the
+invalid fringe that grows inward from the strip edge during a step (one row
+per stencil radius) never reaches the owned rows.  One exchange per step then
+refreshes the halos of F, u, v, p from the neighbours' owned rows:
+
+    per step and interior edge:  4 fields x W rows x pitch x sizeof(T)  each way
+    (8192^2 fp64, W = 16: 4 x 16 x 65.8 KB = 4.2 MB -> ~30 us on one xGMI link)
+
+instead of one 1-row exchange per dependency stage (>= 16 latency-bound
+messages per step).  A halo row is `pitch` contiguous elements, so the rows of
+one field form one contiguous message: send/recv go straight from/to field
+memory (vof_field_view), no packing kernels.  Only point-to-point traffic is
+on the data path -- the reference has no reduction -- so results are identical
+for any strip count.  The residual-terminated pressure solve (extension) adds
+one all-reduce(MAX) of a scalar per check.
+
+torch / torch.distributed are plumbing here (stream handles, P2P ops);
+backend "nccl" is RCCL on ROCm, "gloo" drives the CPU tests.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _abi
+from .engine import Engine, make_desc
+
+EXCHANGED = ("F", "u", "v", "p")
+
+
+def partition(nx, world):
+    """Owned interior rows (lo, hi) of every rank: contiguous, balanced to within one row."""
+    bounds = [(k * nx) // world for k in range(world + 1)]
+    return [(bounds[k] + 1, bounds[k + 1]) for k in range(world)]
+
+
+def stored_rows(nx, own, halo):
+    lo, hi = own
+    return max(0, lo - halo), min(nx + 1, hi + halo)
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can alias library-owned device memory."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class StripSolver:
+    """One rank's strip + the per-step halo exchange."""
+
+    def __init__(self, nx, ny, dtype="f64", ic=1, coord_cast="f32", jacobi_iters=10, rank=0, world=1,
+                 device=None, api=None, dist=None, **consts):
+        import torch
+        self.torch = torch
+        self.dist = dist if dist is not None else (torch.distributed if world > 1 else None)
+        if api is None:
+            from ._lib import hip_api
+            api = hip_api()
+        self.api = api
+        self.on_gpu = api.backend() == b"hip-gfx950"
+        self.rank, self.world = rank, world
+        self.nx, self.ny = nx, ny
+        self.halo = _abi.halo_rows(jacobi_iters)
+        parts = partition(nx, world)
+        if min(hi - lo + 1 for lo, hi in parts) < self.halo:
+            raise ValueError("strips of %d rows are thinner than the %d-row halo" % (nx // world, self.halo))
+        self.own = parts[rank]
+        self.rows = stored_rows(nx, self.own, self.halo)
+        stream_ptr = None
+        self.stream = None
+        if self.on_gpu:
+            dev = torch.device("cuda", device if device is not None else 0)
+            torch.cuda.set_device(dev)
+            # a dedicated non-default stream: hipGraph capture is illegal on the legacy stream, and
+            # torch.distributed orders its RCCL work against the *current* stream
+            self.stream = torch.cuda.Stream(device=dev)
+            stream_ptr = self.stream.cuda_stream
+            self.device = dev
+        desc = make_desc(api, nx, ny, dtype, coord_cast, rows=self.rows, own=self.own,
+                         jacobi_iters=jacobi_iters, device=(device if device is not None else -1) if self.on_gpu else -1,
+                         **consts)
+        self.eng = Engine(api, desc, stream=stream_ptr)
+        self.eng.set_init_F(ic)
+        self._views = {}
+        self._build_views()
+
+    # -- zero-copy tensor views of the exchanged fields -----------------------------
+    def _build_views(self):
+        torch = self.torch
+        tdt = torch.float64 if self.eng.np_dtype == np.float64 else torch.float32
+        typestr = "<f8" if self.eng.np_dtype == np.float64 else "<f4"
+        for f in EXCHANGED:
+            base, pitch, col0, nrows = self.eng.field_view(f)
+            if self.on_gpu:
+                t = torch.as_tensor(_DevArray(base, (nrows, pitch), typestr), device=self.device)
+            else:
+                n = nrows * pitch
+                buf = (ctypes.c_double if tdt == torch.float64 else ctypes.c_float) * n
+                t = torch.from_numpy(np.ctypeslib.as_array(buf.from_address(base))).view(nrows, pitch)
+            assert t.dtype == tdt and t.data_ptr() == base
+            self._views[f] = (t, base)
+
+    def _rows_view(self, f, g0, g1):
+        t, base = self._views[f]
+        cur = self.eng.field_view(f)[0]
+        if cur != base:  # F / p buffers were swapped by single-verb calls: re-alias
+            self._build_views()
+            t, _ = self._views[f]
+        return t[g0 - self.rows[0]: g1 - self.rows[0] + 1]
+
+    # -- exchange ----------------------------------------------------------------------
+    def exchange(self):
+        """Refresh the halo rows of F, u, v, p from both neighbours (one batched P2P group)."""
+        if self.world == 1:
+            return
+        dist, W = self.dist, self.halo
+        lo, hi = self.own
+        ops = []
+        if self.rank > 0:  # lower neighbour owns rows < lo
+            for f in EXCHANGED:
+                ops.append(dist.P2POp(dist.isend, self._rows_view(f, lo, lo + W - 1), self.rank - 1))
+                ops.append(dist.P2POp(dist.irecv, self._rows_view(f, lo - W, lo - 1), self.rank - 1))
+        if self.rank < self.world - 1:
+            for f in EXCHANGED:
+                ops.append(dist.P2POp(dist.isend, self._rows_view(f, hi - W + 1, hi), self.rank + 1))
+                ops.append(dist.P2POp(dist.irecv, self._rows_view(f, hi + 1, hi + W), self.rank + 1))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def _ctx(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()
+
+    def step(self, nsteps=1):
+        with self._ctx():
+            for _ in range(nsteps):
+                self.eng.step(1)
+                self.exchange()
+
+    def solve_p_residual(self, tol, max_iters, check_every=10):
+        """Extension: Jacobi until the global max|p_new - p| <= tol (all-reduce MAX over ranks).
+        Sweeps between checks use 1-row halos refreshed by `exchange` of p only when world > 1."""
+        torch, done, res = self.torch, 0, float("inf")
+        first = True
+        with self._ctx():
+            while done < max_iters:
+                n = min(check_every, max_iters - done, self.halo - 6 if self.world > 1 else check_every)
+                n = max(n - (n & 1), 2)
+                res = self.eng.jacobi_sweeps_residual(n, build_rhs=first)
+                first = False
+                done += n
+                if self.world > 1:
+                    t = torch.tensor([res], dtype=torch.float64, device=self.device if self.on_gpu else "cpu")
+                    self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                    res = float(t.item())
+                    self._exchange_fields(("p",))
+                if res <= tol:
+                    break
+        return done, res
+
+    def _exchange_fields(self, fields):
+        dist, W = self.dist, self.halo
+        lo, hi = self.own
+        ops = []
+        for f in fields:
+            if self.rank > 0:
+                ops.append(dist.P2POp(dist.isend, self._rows_view(f, lo, lo + W - 1), self.rank - 1))
+                ops.append(dist.P2POp(dist.irecv, self._rows_view(f, lo - W, lo - 1), self.rank - 1))
+            if self.rank < self.world - 1:
+                ops.append(dist.P2POp(dist.isend, self._rows_view(f, hi - W + 1, hi), self.rank + 1))
+                ops.append(dist.P2POp(dist.irecv, self._rows_view(f, hi + 1, hi + W), self.rank + 1))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def sync(self):
+        self.eng.sync()
+
+    def owned(self, name):
+        """Owned rows of a field (plus the wall ghost row on the first/last rank), dense numpy."""
+        g0 = 0 if self.own[0] == 1 else self.own[0]
+        g1 = self.nx + 1 if self.own[1] == self.nx else self.own[1]
+        return self.eng.get(name, (g0, g1))
+
+    def gather(self, name):
+        """Full (nx+2, ny+2) field on rank 0 (None elsewhere)."""
+        mine = self.owned(name)
+        if self.world == 1:
+            return mine
+        parts = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(mine, parts, dst=0)
+        return np.concatenate(parts, axis=0) if self.rank == 0 else None
+
+    def close(self):
+        self.eng.close()
