@@ -54,6 +54,19 @@ def load_pmc_traffic(nx, ny, dtype):
     return None
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs but a 16-CPU quota; 256 OpenMP threads then thrash)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(nx, ny, dtype, ic, target_s):
     """The CPU oracle (scalar-C restatement, OpenMP over i, -O2 -ffp-contract=off = the parity
     build) timed on this host's cores on a bounded sample of the same workload."""
@@ -62,8 +75,9 @@ def cpu_baseline(nx, ny, dtype, ic, target_s):
     so = os.path.join(ROOT, "oracle", "_build", "libvof_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)   # read by libgomp when the oracle library loads
     api = _abi.bind(ctypes.CDLL(so), "ovof_", optional=("timer_start", "timer_stop", "time_jacobi"))
-    cores = len(os.sched_getaffinity(0))
     e = Engine(api, make_desc(api, nx, ny, dtype, "f32"))
     e.set_init_F(ic)
     t0 = time.perf_counter()
