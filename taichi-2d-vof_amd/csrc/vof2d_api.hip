@@ -100,6 +100,10 @@ struct vof2d_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t istep = 0;
   int rows_override = 0;
+  int tb = 5;           // Jacobi sweeps fused per launch (1 = plain kernel)
+  int tb_rows = 0;      // rows per wave chunk of the fused kernel (0 = heuristic)
+  int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
+  int fuse_momentum = 1;
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // [istep parity]
   char err[512];
 };
@@ -193,6 +197,17 @@ struct L {
                        h->g, C(h), F_<T>(h, fU), F_<T>(h, fV), F_<T>(h, fKAPPA), F_<T>(h, fF), F_<T>(h, fRHO),
                        F_<T>(h, fNU), F_<T>(h, fUS), F_<T>(h, fVS), R);
   }
+  // fused normals + kappa + predictor + rhs (vof_step only)
+  static void momentum(vof2d_ctx* h) {
+    constexpr int Wt = 64 * V, Ht = ((2 + V - 1) / V) * V, ST = Wt - 2 * Ht;
+    const int ntt = (h->g.ny + ST - 1) / ST;
+    const int rows = h->g.ihi - h->g.ilo + 1;
+    int R = h->mom_rows > 0 ? h->mom_rows : 32;
+    while (R > 16 && (long)((rows + R - 1) / R) * ntt < 4096) R /= 2;
+    hipLaunchKernelGGL((k_momentum<T, V>), dim3(blocks_for(h, ntt, R)), dim3(256), 0, h->stream, h->g, C(h),
+                       F_<T>(h, fF), F_<T>(h, fU), F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R,
+                       ntt);
+  }
   template <bool STORED>
   static void rhs(vof2d_ctx* h) {
     const int R = pick_rows(h, h->g.ntj);
@@ -205,6 +220,17 @@ struct L {
     const int R = pick_rows(h, h->g.ntj);
     hipLaunchKernelGGL((k_jacobi<T, V, 2, RESID>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream,
                        h->g, C(h), F_<T>(h, src), F_<T>(h, fRHS), F_<T>(h, dst), R, h->d_courant + 1);
+  }
+  // TS sweeps src -> dst in one launch
+  template <int TS>
+  static void jacobi_tb(vof2d_ctx* h, int src, int dst) {
+    constexpr int Wt = 64 * V, Ht = ((TS - 1 + V - 1) / V) * V, ST = Wt - 2 * Ht;
+    const int ntt = (h->g.ny + ST - 1) / ST;
+    const int rows = h->g.ihi - h->g.ilo + 1;
+    int R = h->tb_rows > 0 ? h->tb_rows : 32;
+    while (h->tb_rows <= 0 && R > 16 && (long)((rows + R - 1) / R) * ntt < 4096) R /= 2;  // >= ~16 waves per CU
+    hipLaunchKernelGGL((k_jacobi_tb<T, V, TS>), dim3(blocks_for(h, ntt, R)), dim3(256), 0, h->stream, h->g, C(h),
+                       F_<T>(h, src), F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
   }
   template <bool STORED>
   static void correct(vof2d_ctx* h) {
@@ -249,33 +275,50 @@ __global__ void k_copy_interior(Geom g, const T* __restrict__ s, T* __restrict__
   d[o] = s[o];
 }
 
-// n Jacobi sweeps starting from fld[fP]; the result ends in fld[fP] (no pointer swap, so
-// p's ghost cells keep their set_BC values like the reference's copy-back loop :265-266).
+template <typename T>
+void copy_interior(vof2d_ctx* h, int src, int dst) {
+  dim3 grid((h->g.ny + 255) / 256, h->g.ihi - h->g.ilo + 1);
+  hipLaunchKernelGGL(k_copy_interior<T>, grid, dim3(256), 0, h->stream, h->g, F_<T>(h, src), F_<T>(h, dst));
+}
+
+// n Jacobi sweeps starting from fld[fP]; the result ends in fld[fP] (no pointer swap, so p's ghost
+// cells keep their set_BC values like the reference's copy-back loop :265-266).  Sweeps are grouped
+// into launches of h->tb fused sweeps (k_jacobi_tb); the remainder and the residual variant use the
+// single-sweep kernel.
 template <typename T>
 void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
   if (n <= 0) return;
-  int k = 0;
-  if (n & 1) {  // odd: one sweep into pt, copy interior back, then an even number of sweeps
-    if (n == 1 && resid_last) L<T>::template jacobi<true>(h, fP, fPT); else L<T>::template jacobi<false>(h, fP, fPT);
-    dim3 grid((h->g.ny + 255) / 256, h->g.ihi - h->g.ilo + 1);
-    hipLaunchKernelGGL(k_copy_interior<T>, grid, dim3(256), 0, h->stream, h->g, F_<T>(h, fPT), F_<T>(h, fP));
-    k = 1;
+  int cur = fP, oth = fPT;
+  auto flip = [&]() { int t = cur; cur = oth; oth = t; };
+  int left = n;
+  if (resid_last) left -= 1;  // the last sweep carries the max|p_new - p| reduction
+  const int tb = h->tb;
+  while (left > 0) {
+    if (tb >= 10 && left >= 10) { L<T>::template jacobi_tb<10>(h, cur, oth); left -= 10; }
+    else if (tb >= 5 && left >= 5) { L<T>::template jacobi_tb<5>(h, cur, oth); left -= 5; }
+    else if (tb >= 2 && left >= 2) { L<T>::template jacobi_tb<2>(h, cur, oth); left -= 2; }
+    else { L<T>::template jacobi<false>(h, cur, oth); left -= 1; }
+    flip();
   }
-  for (; k < n; k += 2) {
-    L<T>::template jacobi<false>(h, fP, fPT);
-    if (k + 2 >= n && resid_last) L<T>::template jacobi<true>(h, fPT, fP); else L<T>::template jacobi<false>(h, fPT, fP);
-  }
+  if (resid_last) { L<T>::template jacobi<true>(h, cur, oth); flip(); }
+  if (cur != fP) copy_interior<T>(h, fPT, fP);
 }
 
 // the fused per-step schedule, 2dvof.py:506-528 (DESIGN.md "schedule")
 template <typename T>
 void enqueue_step(vof2d_ctx* h, int64_t istep) {
   // cal_nu_rho (:513) is folded into its consumers: rho/nu = f(F[i,j]) recomputed per cell
-  L<T>::normals(h);                       // :514 loop 1
-  L<T>::kappa(h);                         // :514 loop 2
-  L<T>::template predictor<false>(h);     // :517
-  L<T>::template set_bc<false>(h);        // :518
-  L<T>::template rhs<false>(h);           // :521-522, rhs part (iteration invariant)
+  if (h->fuse_momentum) {
+    // :514, :517 and the (sweep-invariant, BC-independent) rhs of :239-241 in one pass
+    L<T>::momentum(h);
+    L<T>::template set_bc<false>(h);      // :518
+  } else {
+    L<T>::normals(h);                     // :514 loop 1
+    L<T>::kappa(h);                       // :514 loop 2
+    L<T>::template predictor<false>(h);   // :517
+    L<T>::template set_bc<false>(h);      // :518
+    L<T>::template rhs<false>(h);         // :521-522, rhs part (iteration invariant)
+  }
   jacobi_n<T>(h, h->d.jacobi_iters, false);  // :521-522
   L<T>::template correct<false>(h);       // :524
   L<T>::template set_bc<false>(h);        // :525
@@ -362,17 +405,18 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   h->nty = (d->ny + (W - 8) - 1) / (W - 8);
   const int align = 128 / (int)h->esz;  // elements per 128 bytes
   g.col0 = align - 1;                   // j = 1 lands on a 128-byte boundary
-  // furthest column any lane touches: marching tiles read j0+V (right neighbour) of the last
-  // tile; y-sweep tiles start at -3 + k*(W-8) and span W columns.
-  long maxcol = 1L + (long)g.ntj * W + h->V;
-  long ycol = -3L + (long)(h->nty - 1) * (W - 8) + W + h->V;
-  if (ycol > maxcol) maxcol = ycol;
-  if (maxcol < d->ny + 2) maxcol = d->ny + 2;
+  // furthest column any lane touches: the overlapped tiles of k_fct_y / k_jacobi_tb start at most
+  // H <= 12 columns left of j = 1 and their last tile may run a full tile past ny.
+  long maxcol = (long)d->ny + W + 16;
   g.pitch = ((g.col0 + maxcol + 1 + align - 1) / align) * align;
   const size_t nrows = (size_t)(d->row_hi - d->row_lo + 1);
   h->field_elems = nrows * (size_t)g.pitch + (size_t)align;  // + one 128-byte tail pad
   const char* ev = getenv("VOF2D_ROWS");
   h->rows_override = ev ? atoi(ev) : 0;
+  if ((ev = getenv("VOF2D_TB"))) h->tb = atoi(ev);
+  if ((ev = getenv("VOF2D_TB_ROWS"))) h->tb_rows = atoi(ev);
+  if ((ev = getenv("VOF2D_FUSE_MOMENTUM"))) h->fuse_momentum = atoi(ev);
+  if ((ev = getenv("VOF2D_MOM_ROWS"))) h->mom_rows = atoi(ev);
 
   int rc = VOF_OK;
   do {
@@ -626,6 +670,16 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
     destroy_graphs(h);
     return VOF_OK;
   }
+  if (!strcmp(name, "jacobi_tb") || !strcmp(name, "jacobi_tb_rows") || !strcmp(name, "momentum_rows") ||
+      !strcmp(name, "fuse_momentum")) {  // tuning knobs
+    if (!strcmp(name, "jacobi_tb")) h->tb = (int)value;
+    else if (!strcmp(name, "jacobi_tb_rows")) h->tb_rows = (int)value;
+    else if (!strcmp(name, "momentum_rows")) h->mom_rows = (int)value;
+    else h->fuse_momentum = (int)value;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    destroy_graphs(h);
+    return VOF_OK;
+  }
   if (!strcmp(name, "rows_per_wave")) {  // tuning knob (0 = heuristic)
     h->rows_override = (int)value;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -645,6 +699,7 @@ int vof_get_param(vof2d_handle h, const char* name, double* value) {
   if (!strcmp(name, "Ly")) { *value = h->d.Ly; return VOF_OK; }
   if (!strcmp(name, "pitch")) { *value = (double)h->g.pitch; return VOF_OK; }
   if (!strcmp(name, "rows_per_wave")) { *value = (double)pick_rows(h, h->g.ntj); return VOF_OK; }
+  if (!strcmp(name, "jacobi_tb")) { *value = (double)h->tb; return VOF_OK; }
   return fail(h, VOF_EINVAL, "unknown parameter");
 }
 int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {

@@ -55,7 +55,7 @@ __device__ __forceinline__ T right_of(const Row<T, V>& w, int q) { return q == V
 template <int V>
 __device__ __forceinline__ bool wave_tile(const Geom& g, int first, int last, int R, int& j0, int& ra,
                                           int& rb) {
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR: rows are wave-uniform
   const int lane = threadIdx.x & 63;
   const int tj = wave % g.ntj;
   const int ch = wave / g.ntj;
@@ -368,6 +368,181 @@ __global__ __launch_bounds__(256) void k_predictor(Geom g, Consts<T> c, const T*
   }
 }
 
+// ------------------------------------------------------------------ fused momentum + rhs
+// get_normal_young (2dvof.py:283-309) + advect_upwind (:206-233) + the rhs of solve_p_jacobi
+// (:239-241) in one pass: F, u, v -> u*, v*, rhs (6 array passes instead of 16).  mx, my and kappa
+// live only in registers.  Pipeline along i with the newest F row r:
+//   N: normals of row r-1   K: kappa of row r-2   P: u*, v* of row r-2   R: rhs of row r-3
+// j+-1 neighbours of computed quantities (my, kappa, v*) come from adjacent lanes by shuffles,
+// which invalidates 2 columns on each tile side (tiles overlap by 2*H, H = 2 rounded up to V).
+// Never-written entries read as 0 exactly like the zero-initialised reference fields (S5):
+// mx/my/kappa outside the interior, u* on wall faces, v* at j = 1 and j = ny+1.
+template <typename T>
+__device__ __forceinline__ void normals_cell(const Consts<T>& c, T Fmm, T Fm0, T Fmp, T F0m, T F00, T F0p, T Fpm,
+                                             T Fp0, T Fpp, T& ox, T& oy) {
+  const T cxn = c.nrm_x, cyn = c.nrm_y;
+  T mx1 = cxn * (Fpp + Fp0 - F0p - F00);
+  T my1 = cyn * (Fpp - Fp0 + F0p - F00);
+  T mx2 = cxn * (Fp0 + Fpm - F00 - F0m);
+  T my2 = cyn * (Fp0 - Fpm + F00 - F0m);
+  T mx3 = cxn * (F00 + F0m - Fm0 - Fmm);
+  T my3 = cyn * (F00 - F0m + Fm0 - Fmm);
+  T mx4 = cxn * (F0p + F00 - Fmp - Fm0);
+  T my4 = cyn * (F0p - F00 + Fmp - Fm0);
+  T mxsum = (mx1 + mx2 + mx3 + mx4) / (T)4;
+  T mysum = (my1 + my2 + my3 + my4) / (T)4;
+  if (dabs<T>(mxsum) < c.tiny && dabs<T>(mysum) < c.tiny) {
+    ox = mxsum;
+    oy = mysum;
+  } else {
+    T magnitude = dsqrt<T>(mxsum * mxsum + mysum * mysum);
+    ox = mxsum / magnitude;
+    oy = mysum / magnitude;
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* __restrict__ F,
+                                                   const T* __restrict__ u, const T* __restrict__ v,
+                                                   T* __restrict__ us, T* __restrict__ vs, T* __restrict__ rhs,
+                                                   int R, int ntt) {
+  constexpr int W = 64 * V;
+  constexpr int H = ((2 + V - 1) / V) * V;
+  constexpr int STRIDE = W - 2 * H;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int tj = wave % ntt, ch = wave / ntt;
+  const int c0 = 1 - H + tj * STRIDE;
+  const int j0 = c0 + lane * V;
+  const int ra = g.ilo + ch * R;
+  if (ra > g.ihi) return;  // wave-uniform
+  const int rb = ra + R - 1 < g.ihi ? ra + R - 1 : g.ihi;
+  const int ny = g.ny, ilo = g.ilo, ihi = g.ihi;
+  const int jlo = c0 + H > 1 ? c0 + H : 1;
+  const int jhi = c0 + W - H - 1 < ny ? c0 + W - H - 1 : ny;
+  const T dt = c.dt, dxi = c.dxi, dyi = c.dyi, dxi2 = c.dxi2, dyi2 = c.dyi2;
+  bool dom[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) dom[q] = (j0 + q) >= 1 && (j0 + q) <= ny;
+  auto rowptr = [&](const T* base, int r) {
+    const int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
+    return base + (size_t)(rc - g.row_lo) * (size_t)g.pitch + (size_t)(g.col0 + j0);
+  };
+  // windows; index names are relative to the newest F row r of the current iteration
+  Row<T, V> F2, F1;            // F rows r-2, r-1 (become r-3.. after the shift)
+  T F3c[V];                    // F row r-3, centre columns
+  Row<T, V> u3, u2, v3, v2;    // u, v rows r-3, r-2 (row r-1 is loaded in the iteration)
+  T mx2[V], mx3[V], my2[V];    // mx rows r-2, r-3; my row r-2
+  T k3[V];                     // kappa row r-3
+  T us3[V], vs3[V];            // u*, v* row r-3
+  const int r0 = ra - 1, r1 = rb + 3;
+  load_row<T, V>(F2, rowptr(F, r0 - 2));
+  load_row<T, V>(F1, rowptr(F, r0 - 1));
+  load_row<T, V>(u3, rowptr(u, r0 - 3));
+  load_row<T, V>(u2, rowptr(u, r0 - 2));
+  load_row<T, V>(v3, rowptr(v, r0 - 3));
+  load_row<T, V>(v2, rowptr(v, r0 - 2));
+#pragma unroll
+  for (int q = 0; q < V; ++q) F3c[q] = mx2[q] = mx3[q] = my2[q] = k3[q] = us3[q] = vs3[q] = (T)0;
+  Row<T, V> Fn, un, vn;  // prefetched: F row r, u / v row r-1
+  load_row<T, V>(Fn, rowptr(F, r0));
+  load_row<T, V>(un, rowptr(u, r0 - 1));
+  load_row<T, V>(vn, rowptr(v, r0 - 1));
+  for (int r = r0; r <= r1; ++r) {
+    const Row<T, V> F0 = Fn, u1 = un, v1 = vn;
+    if (r < r1) {
+      load_row<T, V>(Fn, rowptr(F, r + 1));
+      load_row<T, V>(un, rowptr(u, r));
+      load_row<T, V>(vn, rowptr(v, r));
+    }
+    // ---- N: normals of row r-1 (:285-306)
+    const bool okN = (r - 1) >= ilo && (r - 1) <= ihi;
+    T mx1[V], my1[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      T ox, oy;
+      normals_cell<T>(c, left_of(F2, q), F2.c[q], right_of(F2, q), left_of(F1, q), F1.c[q], right_of(F1, q),
+                      left_of(F0, q), F0.c[q], right_of(F0, q), ox, oy);
+      mx1[q] = (okN && dom[q]) ? ox : (T)0;
+      my1[q] = (okN && dom[q]) ? oy : (T)0;
+    }
+    // ---- K: kappa of row r-2 (:307-309)
+    const bool okK = (r - 2) >= ilo && (r - 2) <= ihi;
+    const T myl = __shfl_up(my2[V - 1], 1, 64), myr = __shfl_down(my2[0], 1, 64);
+    T k2[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const T yr = q == V - 1 ? myr : my2[q + 1], yl = q == 0 ? myl : my2[q - 1];
+      const T kk = -(c.kap_x * (mx1[q] - mx3[q]) + c.kap_y * (yr - yl));
+      k2[q] = (okK && dom[q]) ? kk : (T)0;
+    }
+    // ---- P: u*, v* of row i = r-2 (:206-233)
+    const int i = r - 2;
+    const bool okP = i >= ilo && i <= ihi;
+    const T kl = __shfl_up(k2[V - 1], 1, 64);
+    T us2[V], vs2[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const T u00 = u2.c[q], um0 = u3.c[q], up0 = u1.c[q], u0m = left_of(u2, q), u0p = right_of(u2, q);
+      const T upm = left_of(u1, q);
+      const T v00 = v2.c[q], vm0 = v3.c[q], vp0 = v1.c[q], v0m = left_of(v2, q), v0p = right_of(v2, q);
+      const T vmp = right_of(v3, q);
+      const T F00 = F2.c[q], Fm0 = F3c[q], F0m = left_of(F2, q);
+      const T k00 = k2[q], km0 = k3[q], k0m = q == 0 ? kl : k2[q - 1];
+      const T rho00 = rho_of(c, F00), rhom0 = rho_of(c, Fm0), rho0m = rho_of(c, F0m), nu00 = nu_of(c, F00);
+      T ou, ov;
+      {
+        T v_here = (T)0.25 * (vm0 + vmp + v00 + v0p);
+        T dudx = u00 > 0 ? (u00 - um0) * dxi : (up0 - u00) * dxi;
+        T dudy = v_here > 0 ? (u00 - u0m) * dyi : (u0p - u00) * dyi;
+        T kappa_ave = (k00 + km0) / (T)2.0;
+        T fx_kappa = -c.sigma * (F00 - Fm0) * kappa_ave / c.dx;
+        ou = (u00 + dt * (nu00 * (um0 - (T)2 * u00 + up0) * dxi2 + nu00 * (u0m - (T)2 * u00 + u0p) * dyi2 -
+                          u00 * dudx - v_here * dudy + c.gx + fx_kappa * (T)2 / (rho00 + rhom0)));
+      }
+      {
+        T u_here = (T)0.25 * (u0m + u00 + upm + up0);
+        T dvdx = u_here > 0 ? (v00 - vm0) * dxi : (vp0 - v00) * dxi;
+        T dvdy = v00 > 0 ? (v00 - v0m) * dyi : (v0p - v00) * dyi;
+        T kappa_ave = (k00 + k0m) / (T)2.0;
+        T fy_kappa = -c.sigma * (F00 - F0m) * kappa_ave / c.dy;
+        ov = (v00 + dt * (nu00 * (vm0 - (T)2 * v00 + vp0) * dxi2 + nu00 * (v0m - (T)2 * v00 + v0p) * dyi2 -
+                          u_here * dvdx - v00 * dvdy + c.gy + fy_kappa * (T)2 / (rho00 + rho0m)));
+      }
+      const int j = j0 + q;
+      us2[q] = (okP && i >= 2 && dom[q]) ? ou : (T)0;           // u* exists on i in [2, nx]
+      vs2[q] = (okP && j >= 2 && j <= ny) ? ov : (T)0;          // v* exists on j in [2, ny]
+    }
+    if (i >= ra && i <= rb) {
+      if (i >= 2) store_c<T, V>(us + at(g, i, j0), us2, j0, jlo, jhi);
+      store_c<T, V>(vs + at(g, i, j0), vs2, j0, jlo > 2 ? jlo : 2, jhi);
+    }
+    // ---- R: rhs of row r-3 (:239-241)
+    const int i3 = r - 3;
+    if (i3 >= ra && i3 <= rb) {
+      const T vsr = __shfl_down(vs3[0], 1, 64);
+      T out[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const T vright = q == V - 1 ? vsr : vs3[q + 1];
+        out[q] = rho_of(c, F3c[q]) / c.dt * ((us2[q] - us3[q]) * c.dxi + (vright - vs3[q]) * c.dyi);
+      }
+      store_c<T, V>(rhs + at(g, i3, j0), out, j0, jlo, jhi);
+    }
+    // ---- shift the windows
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      F3c[q] = F2.c[q];
+      mx3[q] = mx2[q]; mx2[q] = mx1[q]; my2[q] = my1[q];
+      k3[q] = k2[q];
+      us3[q] = us2[q]; vs3[q] = vs2[q];
+    }
+    F2 = F1; F1 = F0;
+    u3 = u2; u2 = u1;
+    v3 = v2; v2 = v1;
+  }
+}
+
 // ------------------------------------------------------------------ rhs
 // 2dvof.py:239-241, hoisted out of the Jacobi loop (it does not depend on p;
 // precedent: cal_velocity_div, diff_vof_replaced.py:277-282).
@@ -469,6 +644,162 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) r = vmax(r, __shfl_down(r, s, 64));
     if ((threadIdx.x & 63) == 0 && r > 0.0) atomicMax(resid_bits, (unsigned long long)__double_as_longlong(r));
+  }
+}
+
+// ------------------------------------------------------------------ exact division by a lane constant
+// a / b for a denominator that is constant per lane (ap of the Jacobi stencil).  With
+// y = RN(1/b):  q = RN(a*y);  r = a - b*q (exact, one FMA);  RN(q + r*y) is the correctly rounded
+// quotient (Markstein 1990; the same final step the hardware division expansion performs after
+// its Newton iterations), i.e. bit-identical to IEEE a / b, for 3 FMA-rate ops instead of ~11.
+// Outside a safe exponent window (where r could underflow or q overflow) and for a == 0 the code
+// falls back to the true division / the signed zero of a*y, so every input is handled exactly.
+template <typename T> struct DivLimits;
+template <> struct DivLimits<double> { static constexpr double lo = 1e-280, hi = 1e280; };
+template <> struct DivLimits<float> { static constexpr float lo = 1e-25f, hi = 1e25f; };
+template <typename T> __device__ __forceinline__ T dfma(T a, T b, T c);
+template <> __device__ __forceinline__ double dfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float dfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
+  const T q = a * y;
+  const T r = dfma<T>(-b, q, a);
+  T res = dfma<T>(r, y, q);
+  const T aa = dabs<T>(a);
+  if (!(aa >= DivLimits<T>::lo && aa <= DivLimits<T>::hi)) {
+    res = q;                    // a == 0: signed zero of the quotient
+    if (a != (T)0) res = a / b;  // tiny / huge / non-finite numerators: hardware-exact path
+  }
+  return res;
+}
+
+// ------------------------------------------------------------------ Jacobi, TS sweeps per launch
+// Temporal blocking of 2dvof.py:258-266.  The reference runs a fixed number of sweeps (10, :521)
+// with a sweep-invariant rhs, so TS consecutive sweeps can be applied while a tile streams through
+// registers once: stage s (= sweep s of this launch) trails stage s-1 by one row.  HBM traffic per
+// launch stays 3 arrays (read p, read rhs, write p_TS) for TS sweeps.  Each cell value is computed
+// by the same expression, in the same order, from the same operands as TS single sweeps, so the
+// result is identical.  A wave owns 64*V columns; intermediate sweeps exchange their j+-1
+// neighbours across lanes by shuffles, which costs TS-1 invalid columns on each tile side
+// (tiles overlap by 2*H, H = TS-1 rounded up to V) and TS rows of lead-in/lead-out per chunk.
+template <typename T, int V, int TS>
+__global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
+                                                    const T* __restrict__ rhs, T* __restrict__ pn, int R,
+                                                    int ntt) {
+  constexpr int W = 64 * V;
+  constexpr int H = ((TS - 1 + V - 1) / V) * V;
+  constexpr int STRIDE = W - 2 * H;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR: rows are wave-uniform
+  const int lane = threadIdx.x & 63;
+  const int tj = wave % ntt, ch = wave / ntt;
+  const int c0 = 1 - H + tj * STRIDE;
+  const int j0 = c0 + lane * V;
+  const int ra = g.ilo + ch * R;
+  if (ra > g.ihi) return;  // wave-uniform
+  const int rb = ra + R - 1 < g.ihi ? ra + R - 1 : g.ihi;
+  const int nx = g.nx, ny = g.ny, ilo = g.ilo, ihi = g.ihi;
+  const int jlo = c0 + H > 1 ? c0 + H : 1;
+  const int jhi = c0 + W - H - 1 < ny ? c0 + W - H - 1 : ny;
+  const int64_t pitch = g.pitch;
+
+  T an[V], as_[V], apI[V], yI[V];
+  bool dom[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const int j = j0 + q;
+    dom[q] = j >= 1 && j <= ny;
+    an[q] = j != ny ? c.dyi2 : (T)0.0;
+    as_[q] = j != 1 ? c.dyi2 : (T)0.0;
+    apI[q] = (T)-1.0 * (c.dxi2 + c.dxi2 + an[q] + as_[q]);  // ap of rows 1 < i < nx
+    yI[q] = (T)1 / apI[q];
+  }
+  auto rowptr = [&](const T* base, int r) {
+    const int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
+    return base + (size_t)(rc - g.row_lo) * (size_t)pitch + (size_t)(g.col0 + j0);
+  };
+
+  T m[TS][V], cc[TS][V], rq[TS][V];
+#pragma unroll
+  for (int s = 0; s < TS; ++s)
+#pragma unroll
+    for (int q = 0; q < V; ++q) m[s][q] = cc[s][q] = rq[s][q] = (T)0;
+  const int t0 = ra - TS + 2, t1 = rb + TS;
+  T cl1, cr1;  // side neighbours of cc[0] (input row t-1), from memory
+  load_c<T, V>(m[0], rowptr(p, t0 - 2));
+  {
+    const T* q1 = rowptr(p, t0 - 1);
+    load_c<T, V>(cc[0], q1);
+    cl1 = q1[-1];
+    cr1 = q1[V];
+  }
+  // rq[s-1] must hold rhs[t-s] when stage s runs; rows t0-2 .. t0-TS are only used by stages whose
+  // output is still in the lead-in (discarded), so the queue starts empty.
+  Row<T, V> nxt;  // input row t (prefetched one iteration ahead)
+  T nb[V];        // rhs row t-1
+  load_row<T, V>(nxt, rowptr(p, t0));
+  load_c<T, V>(nb, rowptr(rhs, t0 - 1));
+  for (int t = t0; t <= t1; ++t) {
+    Row<T, V> e0 = nxt;
+    T b0[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) b0[q] = nb[q];
+    if (t < t1) {  // prefetch the next iteration's rows
+      load_row<T, V>(nxt, rowptr(p, t + 1));
+      load_c<T, V>(nb, rowptr(rhs, t));
+    }
+#pragma unroll
+    for (int s = TS - 1; s > 0; --s)
+#pragma unroll
+      for (int q = 0; q < V; ++q) rq[s][q] = rq[s - 1][q];
+#pragma unroll
+    for (int q = 0; q < V; ++q) rq[0][q] = b0[q];
+    T carry[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) carry[q] = e0.c[q];
+#pragma unroll
+    for (int s = 1; s <= TS; ++s) {
+      const int i = t - s;  // row this stage produces
+      T sl, sr;             // P_{s-1}[i][j0-1], P_{s-1}[i][j0+V]
+      if (s == 1) {
+        sl = cl1;
+        sr = cr1;
+      } else {
+        sl = __shfl_up(cc[s - 1][V - 1], 1, 64);
+        sr = __shfl_down(cc[s - 1][0], 1, 64);
+      }
+      const bool rowok = i >= ilo && i <= ihi;
+      const bool edge = (i == 1) || (i == nx);
+      const T ae = i != nx ? c.dxi2 : (T)0.0;
+      const T aw = i != 1 ? c.dxi2 : (T)0.0;
+      T out[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const T N = q == V - 1 ? sr : cc[s - 1][q + 1];
+        const T S = q == 0 ? sl : cc[s - 1][q - 1];
+        const T num = rq[s - 1][q] - ae * carry[q] - aw * m[s - 1][q] - an[q] * N - as_[q] * S;
+        T o;
+        if (edge) {  // wave-uniform: first / last interior row has its own ap
+          const T ap = (T)-1.0 * (ae + aw + an[q] + as_[q]);
+          o = num / ap;
+        } else {
+          o = div_by_const<T>(num, apI[q], yI[q]);
+        }
+        out[q] = (rowok && dom[q]) ? o : (T)0;
+      }
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        m[s - 1][q] = cc[s - 1][q];
+        cc[s - 1][q] = carry[q];
+        carry[q] = out[q];
+      }
+      if (s == 1) {
+        cl1 = e0.l;
+        cr1 = e0.r;
+      }
+    }
+    const int io = t - TS;
+    if (io >= ra && io <= rb) store_c<T, V>(pn + at(g, io, j0), carry, j0, jlo, jhi);
   }
 }
 
@@ -659,7 +990,7 @@ template <typename T, int V, bool POST>
 __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __restrict__ F,
                                                 const T* __restrict__ v, T* __restrict__ Fn, int R, int nty) {
   constexpr int W = 64 * V, STRIDE = W - 8;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR: rows are wave-uniform
   const int lane = threadIdx.x & 63;
   const int tj = wave % nty, ch = wave / nty;
   const int c0 = -3 + tj * STRIDE;
