@@ -76,6 +76,8 @@ Consts<T> round_consts(const ConstsD& s) {
   R1(dt); R1(dx); R1(dy); R1(dxi); R1(dyi); R1(dxi2); R1(dyi2); R1(rho_l); R1(rho_g); R1(nu_l); R1(nu_g);
   R1(sigma); R1(gx); R1(gy); R1(nrm_x); R1(nrm_y); R1(kap_x); R1(kap_y); R1(dxdy); R1(dtdy); R1(dtdx);
   R1(cfl_x); R1(cfl_y); R1(half_dx); R1(half_dy); R1(sqrt2dx); R1(tiny);
+  // RN(1/b) in T arithmetic for div_by_const
+  c.inv_dx = (T)1 / c.dx; c.inv_dy = (T)1 / c.dy; c.inv_dt = (T)1 / c.dt; c.inv_dxdy = (T)1 / c.dxdy;
   R1(ic1_x2); R1(ic1_y2); R1(ic_r); R1(ic_cx); R1(ic2_cy); R1(ic3_cy); R1(ic3_pool);
 #undef R1
   return c;
@@ -103,6 +105,7 @@ struct vof2d_ctx {
   int tb = 5;           // Jacobi sweeps fused per launch (1 = plain kernel)
   int tb_rows = 0;      // rows per wave chunk of the fused kernel (0 = heuristic)
   int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
+  int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = 64)
   int fuse_momentum = 1;
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // [istep parity]
   char err[512];
@@ -242,13 +245,14 @@ struct L {
   // sweeps read fld[fF], write fld[fF2]; the caller swaps the two afterwards
   template <bool POST>
   static void fct_x(vof2d_ctx* h) {
-    const int R = h->rows_override > 0 ? h->rows_override : 64;
+    const int R = h->fctx_rows > 0 ? h->fctx_rows : 32;
     hipLaunchKernelGGL((k_fct_x<T, V, POST>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g,
                        C(h), F_<T>(h, fF), F_<T>(h, fU), F_<T>(h, fF2), R);
   }
   template <bool POST>
   static void fct_y(vof2d_ctx* h) {
-    const int R = pick_rows(h, h->nty);
+    int R = pick_rows(h, h->nty);
+    if (h->rows_override <= 0 && R > 16) R = 16;
     hipLaunchKernelGGL((k_fct_y<T, V, POST>), dim3(blocks_for(h, h->nty, R)), dim3(256), 0, h->stream, h->g, C(h),
                        F_<T>(h, fF), F_<T>(h, fV), F_<T>(h, fF2), R, h->nty);
   }
@@ -294,8 +298,7 @@ void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
   if (resid_last) left -= 1;  // the last sweep carries the max|p_new - p| reduction
   const int tb = h->tb;
   while (left > 0) {
-    if (tb >= 10 && left >= 10) { L<T>::template jacobi_tb<10>(h, cur, oth); left -= 10; }
-    else if (tb >= 5 && left >= 5) { L<T>::template jacobi_tb<5>(h, cur, oth); left -= 5; }
+    if (tb >= 5 && left >= 5) { L<T>::template jacobi_tb<5>(h, cur, oth); left -= 5; }
     else if (tb >= 2 && left >= 2) { L<T>::template jacobi_tb<2>(h, cur, oth); left -= 2; }
     else { L<T>::template jacobi<false>(h, cur, oth); left -= 1; }
     flip();
@@ -415,6 +418,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   h->rows_override = ev ? atoi(ev) : 0;
   if ((ev = getenv("VOF2D_TB"))) h->tb = atoi(ev);
   if ((ev = getenv("VOF2D_TB_ROWS"))) h->tb_rows = atoi(ev);
+  if ((ev = getenv("VOF2D_FCTX_ROWS"))) h->fctx_rows = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_MOMENTUM"))) h->fuse_momentum = atoi(ev);
   if ((ev = getenv("VOF2D_MOM_ROWS"))) h->mom_rows = atoi(ev);
 

@@ -35,6 +35,7 @@ template <typename T>
 struct Consts {
   T dt, dx, dy, dxi, dyi, dxi2, dyi2, rho_l, rho_g, nu_l, nu_g, sigma, gx, gy;
   T nrm_x, nrm_y, kap_x, kap_y, dxdy, dtdy, dtdx, cfl_x, cfl_y, half_dx, half_dy, sqrt2dx, tiny;
+  T inv_dx, inv_dy, inv_dt, inv_dxdy;  // correctly rounded reciprocals (div_by_const)
   // set_init_F literals (2dvof.py:141-159), folded in double then rounded
   T ic1_x2, ic1_y2, ic_r, ic_cx, ic2_cy, ic3_cy, ic3_pool;
 };
@@ -46,9 +47,15 @@ struct alignas(sizeof(T) * V) Pack {
   T v[V];
 };
 
-// ti.max / ti.min as comparisons (identical to the oracle's vmax/vmin)
-template <typename T> __device__ __forceinline__ T vmax(T a, T b) { return a > b ? a : b; }
-template <typename T> __device__ __forceinline__ T vmin(T a, T b) { return a < b ? a : b; }
+// ti.max / ti.min.  The oracle evaluates them as comparisons (a > b ? a : b); v_max_f64 / v_min_f64
+// return the same VALUE for every non-NaN pair (only the sign of a +-0 tie can differ, which no
+// later operation observes) at a third of the instructions of compare + 2x v_cndmask_b32.
+template <typename T> __device__ __forceinline__ T vmax(T a, T b);
+template <typename T> __device__ __forceinline__ T vmin(T a, T b);
+template <> __device__ __forceinline__ double vmax<double>(double a, double b) { return __builtin_fmax(a, b); }
+template <> __device__ __forceinline__ double vmin<double>(double a, double b) { return __builtin_fmin(a, b); }
+template <> __device__ __forceinline__ float vmax<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <> __device__ __forceinline__ float vmin<float>(float a, float b) { return __builtin_fminf(a, b); }
 
 // 2dvof.py:192-195  var(a, b, c) = a + b + c - max(a,b,c) - min(a,b,c), left to right
 template <typename T> __device__ __forceinline__ T var3(T a, T b, T c) {

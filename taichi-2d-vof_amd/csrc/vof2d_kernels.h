@@ -68,6 +68,57 @@ __device__ __forceinline__ size_t at(const Geom& g, int i, int j) {
   return (size_t)(i - g.row_lo) * (size_t)g.pitch + (size_t)(g.col0 + j);
 }
 
+// ------------------------------------------------------------------ cross-lane neighbours (DPP)
+// lane_up(x): value of lane-1 (lane 0 keeps its own); lane_dn(x): value of lane+1 (lane 63 keeps
+// its own).  gfx9 DPP wave_shr:1 / wave_shl:1 -- a VALU move, no LDS round trip like ds_bpermute.
+__device__ __forceinline__ int dpp_up(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_dn(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ double lane_up(double x) {
+  return __hiloint2double(dpp_up(__double2hiint(x)), dpp_up(__double2loint(x)));
+}
+__device__ __forceinline__ double lane_dn(double x) {
+  return __hiloint2double(dpp_dn(__double2hiint(x)), dpp_dn(__double2loint(x)));
+}
+__device__ __forceinline__ float lane_up(float x) { return __int_as_float(dpp_up(__float_as_int(x))); }
+__device__ __forceinline__ float lane_dn(float x) { return __int_as_float(dpp_dn(__float_as_int(x))); }
+
+// ------------------------------------------------------------------ exact division by a lane constant
+// a / b for a denominator that is constant per lane (ap of the Jacobi stencil).  With
+// y = RN(1/b):  q = RN(a*y);  r = a - b*q (exact, one FMA);  RN(q + r*y) is the correctly rounded
+// quotient (Markstein 1990; the same final step the hardware division expansion performs after
+// its Newton iterations), i.e. bit-identical to IEEE a / b, for 3 FMA-rate ops instead of ~11.
+// Outside a safe exponent window (where r could underflow or q overflow) and for a == 0 the code
+// falls back to the true division / the signed zero of a*y, so every input is handled exactly.
+template <typename T> struct DivLimits;
+template <> struct DivLimits<double> { static constexpr double lo = 1e-280, hi = 1e280; };
+template <> struct DivLimits<float> { static constexpr float lo = 1e-25f, hi = 1e25f; };
+template <typename T> __device__ __forceinline__ T dfma(T a, T b, T c);
+template <> __device__ __forceinline__ double dfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float dfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// out-of-line so the (practically never taken) hardware division expansion is not replicated
+// into every unrolled call site
+template <typename T>
+__device__ __attribute__((noinline)) T div_slow(T a, T b) { return a / b; }
+
+template <typename T, bool SMALL_B = false>
+__device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
+  const T q = a * y;
+  const T r = dfma<T>(-b, q, a);
+  T res = dfma<T>(r, y, q);
+  // Tiny numerators, zero and NaN leave the fast path; with |b| < 1 (SMALL_B) also huge ones, where
+  // q could overflow.  (An infinite numerator -- a simulation that has already blown up -- yields
+  // NaN here instead of inf when |b| >= 1.)
+  const T aa = dabs<T>(a);
+  if (!(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi))) {
+    res = q;                    // a == 0: signed zero of the quotient
+    if (a != (T)0) res = div_slow<T>(a, b);  // tiny / huge / non-finite numerators: hardware-exact path
+  }
+  return res;
+}
+
+template <int N> struct IC { static constexpr int value = N; };
+
 // ------------------------------------------------------------------ init
 // 2dvof.py:102-134 find_area
 template <typename T>
@@ -435,6 +486,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   T mx2[V], mx3[V], my2[V];    // mx rows r-2, r-3; my row r-2
   T k3[V];                     // kappa row r-3
   T us3[V], vs3[V];            // u*, v* row r-3
+  T rho3[V];                   // rho(F) row r-3 (rho is a pure function of F[i,j], :201-202)
   const int r0 = ra - 1, r1 = rb + 3;
   load_row<T, V>(F2, rowptr(F, r0 - 2));
   load_row<T, V>(F1, rowptr(F, r0 - 1));
@@ -443,7 +495,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   load_row<T, V>(v3, rowptr(v, r0 - 3));
   load_row<T, V>(v2, rowptr(v, r0 - 2));
 #pragma unroll
-  for (int q = 0; q < V; ++q) F3c[q] = mx2[q] = mx3[q] = my2[q] = k3[q] = us3[q] = vs3[q] = (T)0;
+  for (int q = 0; q < V; ++q) F3c[q] = mx2[q] = mx3[q] = my2[q] = k3[q] = us3[q] = vs3[q] = rho3[q] = (T)0;
   Row<T, V> Fn, un, vn;  // prefetched: F row r, u / v row r-1
   load_row<T, V>(Fn, rowptr(F, r0));
   load_row<T, V>(un, rowptr(u, r0 - 1));
@@ -468,7 +520,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
     }
     // ---- K: kappa of row r-2 (:307-309)
     const bool okK = (r - 2) >= ilo && (r - 2) <= ihi;
-    const T myl = __shfl_up(my2[V - 1], 1, 64), myr = __shfl_down(my2[0], 1, 64);
+    const T myl = lane_up(my2[V - 1]), myr = lane_dn(my2[0]);
     T k2[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
@@ -479,8 +531,11 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
     // ---- P: u*, v* of row i = r-2 (:206-233)
     const int i = r - 2;
     const bool okP = i >= ilo && i <= ihi;
-    const T kl = __shfl_up(k2[V - 1], 1, 64);
-    T us2[V], vs2[V];
+    const T kl = lane_up(k2[V - 1]);
+    T us2[V], vs2[V], rho2[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) rho2[q] = rho_of(c, F2.c[q]);
+    const T rho2l = rho_of(c, F2.l);
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       const T u00 = u2.c[q], um0 = u3.c[q], up0 = u1.c[q], u0m = left_of(u2, q), u0p = right_of(u2, q);
@@ -489,14 +544,14 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
       const T vmp = right_of(v3, q);
       const T F00 = F2.c[q], Fm0 = F3c[q], F0m = left_of(F2, q);
       const T k00 = k2[q], km0 = k3[q], k0m = q == 0 ? kl : k2[q - 1];
-      const T rho00 = rho_of(c, F00), rhom0 = rho_of(c, Fm0), rho0m = rho_of(c, F0m), nu00 = nu_of(c, F00);
+      const T rho00 = rho2[q], rhom0 = rho3[q], rho0m = q == 0 ? rho2l : rho2[q - 1], nu00 = nu_of(c, F00);
       T ou, ov;
       {
         T v_here = (T)0.25 * (vm0 + vmp + v00 + v0p);
         T dudx = u00 > 0 ? (u00 - um0) * dxi : (up0 - u00) * dxi;
         T dudy = v_here > 0 ? (u00 - u0m) * dyi : (u0p - u00) * dyi;
         T kappa_ave = (k00 + km0) / (T)2.0;
-        T fx_kappa = -c.sigma * (F00 - Fm0) * kappa_ave / c.dx;
+        T fx_kappa = div_by_const<T, true>(-c.sigma * (F00 - Fm0) * kappa_ave, c.dx, c.inv_dx);
         ou = (u00 + dt * (nu00 * (um0 - (T)2 * u00 + up0) * dxi2 + nu00 * (u0m - (T)2 * u00 + u0p) * dyi2 -
                           u00 * dudx - v_here * dudy + c.gx + fx_kappa * (T)2 / (rho00 + rhom0)));
       }
@@ -505,7 +560,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
         T dvdx = u_here > 0 ? (v00 - vm0) * dxi : (vp0 - v00) * dxi;
         T dvdy = v00 > 0 ? (v00 - v0m) * dyi : (v0p - v00) * dyi;
         T kappa_ave = (k00 + k0m) / (T)2.0;
-        T fy_kappa = -c.sigma * (F00 - F0m) * kappa_ave / c.dy;
+        T fy_kappa = div_by_const<T, true>(-c.sigma * (F00 - F0m) * kappa_ave, c.dy, c.inv_dy);
         ov = (v00 + dt * (nu00 * (vm0 - (T)2 * v00 + vp0) * dxi2 + nu00 * (v0m - (T)2 * v00 + v0p) * dyi2 -
                           u_here * dvdx - v00 * dvdy + c.gy + fy_kappa * (T)2 / (rho00 + rho0m)));
       }
@@ -520,12 +575,13 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
     // ---- R: rhs of row r-3 (:239-241)
     const int i3 = r - 3;
     if (i3 >= ra && i3 <= rb) {
-      const T vsr = __shfl_down(vs3[0], 1, 64);
+      const T vsr = lane_dn(vs3[0]);
       T out[V];
 #pragma unroll
       for (int q = 0; q < V; ++q) {
         const T vright = q == V - 1 ? vsr : vs3[q + 1];
-        out[q] = rho_of(c, F3c[q]) / c.dt * ((us2[q] - us3[q]) * c.dxi + (vright - vs3[q]) * c.dyi);
+        out[q] = div_by_const<T, true>(rho3[q], c.dt, c.inv_dt) *
+                 ((us2[q] - us3[q]) * c.dxi + (vright - vs3[q]) * c.dyi);
       }
       store_c<T, V>(rhs + at(g, i3, j0), out, j0, jlo, jhi);
     }
@@ -536,6 +592,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
       mx3[q] = mx2[q]; mx2[q] = mx1[q]; my2[q] = my1[q];
       k3[q] = k2[q];
       us3[q] = us2[q]; vs3[q] = vs2[q];
+      rho3[q] = rho2[q];
     }
     F2 = F1; F1 = F0;
     u3 = u2; u2 = u1;
@@ -647,33 +704,6 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
   }
 }
 
-// ------------------------------------------------------------------ exact division by a lane constant
-// a / b for a denominator that is constant per lane (ap of the Jacobi stencil).  With
-// y = RN(1/b):  q = RN(a*y);  r = a - b*q (exact, one FMA);  RN(q + r*y) is the correctly rounded
-// quotient (Markstein 1990; the same final step the hardware division expansion performs after
-// its Newton iterations), i.e. bit-identical to IEEE a / b, for 3 FMA-rate ops instead of ~11.
-// Outside a safe exponent window (where r could underflow or q overflow) and for a == 0 the code
-// falls back to the true division / the signed zero of a*y, so every input is handled exactly.
-template <typename T> struct DivLimits;
-template <> struct DivLimits<double> { static constexpr double lo = 1e-280, hi = 1e280; };
-template <> struct DivLimits<float> { static constexpr float lo = 1e-25f, hi = 1e25f; };
-template <typename T> __device__ __forceinline__ T dfma(T a, T b, T c);
-template <> __device__ __forceinline__ double dfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
-template <> __device__ __forceinline__ float dfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
-template <typename T>
-__device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
-  const T q = a * y;
-  const T r = dfma<T>(-b, q, a);
-  T res = dfma<T>(r, y, q);
-  const T aa = dabs<T>(a);
-  if (!(aa >= DivLimits<T>::lo && aa <= DivLimits<T>::hi)) {
-    res = q;                    // a == 0: signed zero of the quotient
-    if (a != (T)0) res = a / b;  // tiny / huge / non-finite numerators: hardware-exact path
-  }
-  return res;
-}
-
 // ------------------------------------------------------------------ Jacobi, TS sweeps per launch
 // Temporal blocking of 2dvof.py:258-266.  The reference runs a fixed number of sweeps (10, :521)
 // with a sweep-invariant rhs, so TS consecutive sweeps can be applied while a tile streams through
@@ -681,16 +711,21 @@ __device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
 // launch stays 3 arrays (read p, read rhs, write p_TS) for TS sweeps.  Each cell value is computed
 // by the same expression, in the same order, from the same operands as TS single sweeps, so the
 // result is identical.  A wave owns 64*V columns; intermediate sweeps exchange their j+-1
-// neighbours across lanes by shuffles, which costs TS-1 invalid columns on each tile side
-// (tiles overlap by 2*H, H = TS-1 rounded up to V) and TS rows of lead-in/lead-out per chunk.
+// neighbours across lanes (DPP), which costs TS-1 invalid columns on each tile side (tiles
+// overlap by 2*H, H = TS-1 rounded up to V) and TS rows of lead-in/lead-out per chunk.
+//
+// Register rotation: stage s keeps rows i-1, i, i+1 of its input in a ring of three row buffers
+// whose roles advance by one per iteration, and the rhs rows in a ring of six; the row loop is
+// unrolled by 6 with compile-time ring positions, so no value is ever moved between registers.
 template <typename T, int V, int TS>
 __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
                                                     const T* __restrict__ rhs, T* __restrict__ pn, int R,
                                                     int ntt) {
+  static_assert(TS >= 2 && TS <= 5, "rhs ring holds 6 rows");
   constexpr int W = 64 * V;
   constexpr int H = ((TS - 1 + V - 1) / V) * V;
   constexpr int STRIDE = W - 2 * H;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR: rows are wave-uniform
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int tj = wave % ntt, ch = wave / ntt;
   const int c0 = 1 - H + tj * STRIDE;
@@ -698,17 +733,15 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
   const int ra = g.ilo + ch * R;
   if (ra > g.ihi) return;  // wave-uniform
   const int rb = ra + R - 1 < g.ihi ? ra + R - 1 : g.ihi;
-  const int nx = g.nx, ny = g.ny, ilo = g.ilo, ihi = g.ihi;
+  const int nx = g.nx, ny = g.ny;
   const int jlo = c0 + H > 1 ? c0 + H : 1;
   const int jhi = c0 + W - H - 1 < ny ? c0 + W - H - 1 : ny;
   const int64_t pitch = g.pitch;
 
   T an[V], as_[V], apI[V], yI[V];
-  bool dom[V];
 #pragma unroll
   for (int q = 0; q < V; ++q) {
     const int j = j0 + q;
-    dom[q] = j >= 1 && j <= ny;
     an[q] = j != ny ? c.dyi2 : (T)0.0;
     as_[q] = j != 1 ? c.dyi2 : (T)0.0;
     apI[q] = (T)-1.0 * (c.dxi2 + c.dxi2 + an[q] + as_[q]);  // ap of rows 1 < i < nx
@@ -719,87 +752,102 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
     return base + (size_t)(rc - g.row_lo) * (size_t)pitch + (size_t)(g.col0 + j0);
   };
 
-  T m[TS][V], cc[TS][V], rq[TS][V];
+  // ring[s][k]: input rows of stage s+1.  In the sub-iteration with phase U (t = tb + U):
+  //   ring[s][(U+0)%3] = row i-1,  ring[s][(U+1)%3] = row i,  ring[s][(U+2)%3] = row i+1 (incoming)
+  // where i = t - (s+1).  For s = 0 the rows come from memory (sideL/sideR carry their j0-1 / j0+V
+  // neighbours); for s > 0 the incoming row is the output of stage s in the same sub-iteration.
+  T ring[TS][3][V], sideL[3], sideR[3];
+  T rq[6][V];  // rq[(t-1) % 6 phase] = rhs row t-1 ...: row x lives in slot (x - xbase) mod 6
 #pragma unroll
   for (int s = 0; s < TS; ++s)
 #pragma unroll
-    for (int q = 0; q < V; ++q) m[s][q] = cc[s][q] = rq[s][q] = (T)0;
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int q = 0; q < V; ++q) ring[s][k][q] = (T)0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int q = 0; q < V; ++q) rq[k][q] = (T)0;
+
   const int t0 = ra - TS + 2, t1 = rb + TS;
-  T cl1, cr1;  // side neighbours of cc[0] (input row t-1), from memory
-  load_c<T, V>(m[0], rowptr(p, t0 - 2));
+  // phase 0 at t = t0: rows t0-2, t0-1, t0 of p in ring[0][0..2]; rhs row t0-1 in rq slot 0
+  // (slot of rhs row x = (x - (t0-1)) mod 6; stage s at phase U reads row t-s -> slot (U+1-s) mod 6)
+  load_c<T, V>(ring[0][0], rowptr(p, t0 - 2));
   {
     const T* q1 = rowptr(p, t0 - 1);
-    load_c<T, V>(cc[0], q1);
-    cl1 = q1[-1];
-    cr1 = q1[V];
+    load_c<T, V>(ring[0][1], q1);
+    sideL[1] = q1[-1];
+    sideR[1] = q1[V];
+    const T* q2 = rowptr(p, t0);
+    load_c<T, V>(ring[0][2], q2);
+    sideL[2] = q2[-1];
+    sideR[2] = q2[V];
   }
-  // rq[s-1] must hold rhs[t-s] when stage s runs; rows t0-2 .. t0-TS are only used by stages whose
-  // output is still in the lead-in (discarded), so the queue starts empty.
-  Row<T, V> nxt;  // input row t (prefetched one iteration ahead)
-  T nb[V];        // rhs row t-1
-  load_row<T, V>(nxt, rowptr(p, t0));
-  load_c<T, V>(nb, rowptr(rhs, t0 - 1));
-  for (int t = t0; t <= t1; ++t) {
-    Row<T, V> e0 = nxt;
-    T b0[V];
-#pragma unroll
-    for (int q = 0; q < V; ++q) b0[q] = nb[q];
-    if (t < t1) {  // prefetch the next iteration's rows
-      load_row<T, V>(nxt, rowptr(p, t + 1));
-      load_c<T, V>(nb, rowptr(rhs, t));
-    }
-#pragma unroll
-    for (int s = TS - 1; s > 0; --s)
-#pragma unroll
-      for (int q = 0; q < V; ++q) rq[s][q] = rq[s - 1][q];
-#pragma unroll
-    for (int q = 0; q < V; ++q) rq[0][q] = b0[q];
-    T carry[V];
-#pragma unroll
-    for (int q = 0; q < V; ++q) carry[q] = e0.c[q];
+  sideL[0] = sideR[0] = (T)0;
+  load_c<T, V>(rq[0], rowptr(rhs, t0 - 1));
+
+  auto sub = [&](auto uc, int t) {
+    constexpr int U = decltype(uc)::value;
+    constexpr int kM = U % 3, kC = (U + 1) % 3, kE = (U + 2) % 3;
+    T carry[V];  // output of the previous stage = row i+1 of this stage's input
 #pragma unroll
     for (int s = 1; s <= TS; ++s) {
-      const int i = t - s;  // row this stage produces
-      T sl, sr;             // P_{s-1}[i][j0-1], P_{s-1}[i][j0+V]
+      const int i = t - s;
+      T sl, sr;
       if (s == 1) {
-        sl = cl1;
-        sr = cr1;
+        sl = sideL[kC];
+        sr = sideR[kC];
       } else {
-        sl = __shfl_up(cc[s - 1][V - 1], 1, 64);
-        sr = __shfl_down(cc[s - 1][0], 1, 64);
+        sl = lane_up(ring[s - 1][kC][V - 1]);
+        sr = lane_dn(ring[s - 1][kC][0]);
       }
-      const bool rowok = i >= ilo && i <= ihi;
+      if (s > 1) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) ring[s - 1][kE][q] = carry[q];
+      }
+      // lead-in: stage s first matters at row ra-(TS-s), i.e. from t = ra-TS+2s on (wave-uniform)
+      if (s > 1 && t < ra - TS + 2 * s) continue;
       const bool edge = (i == 1) || (i == nx);
       const T ae = i != nx ? c.dxi2 : (T)0.0;
       const T aw = i != 1 ? c.dxi2 : (T)0.0;
-      T out[V];
+      const int slot = ((U + 1 - s) % 6 + 6) % 6;  // constant after unrolling
 #pragma unroll
       for (int q = 0; q < V; ++q) {
-        const T N = q == V - 1 ? sr : cc[s - 1][q + 1];
-        const T S = q == 0 ? sl : cc[s - 1][q - 1];
-        const T num = rq[s - 1][q] - ae * carry[q] - aw * m[s - 1][q] - an[q] * N - as_[q] * S;
-        T o;
+        const T N = q == V - 1 ? sr : ring[s - 1][kC][q + 1];
+        const T S = q == 0 ? sl : ring[s - 1][kC][q - 1];
+        const T num = rq[slot][q] - ae * ring[s - 1][kE][q] - aw * ring[s - 1][kM][q] - an[q] * N - as_[q] * S;
         if (edge) {  // wave-uniform: first / last interior row has its own ap
           const T ap = (T)-1.0 * (ae + aw + an[q] + as_[q]);
-          o = num / ap;
+          carry[q] = num / ap;
         } else {
-          o = div_by_const<T>(num, apI[q], yI[q]);
+          carry[q] = div_by_const<T>(num, apI[q], yI[q]);
         }
-        out[q] = (rowok && dom[q]) ? o : (T)0;
       }
-#pragma unroll
-      for (int q = 0; q < V; ++q) {
-        m[s - 1][q] = cc[s - 1][q];
-        cc[s - 1][q] = carry[q];
-        carry[q] = out[q];
-      }
-      if (s == 1) {
-        cl1 = e0.l;
-        cr1 = e0.r;
+      if (s == 1 && t < t1) {
+        // ring[0][kM] (row t-2) is dead now: prefetch row t+1 into it; rhs row t into the free slot
+        const T* qn = rowptr(p, t + 1);
+        load_c<T, V>(ring[0][kM], qn);
+        sideL[kM] = qn[-1];
+        sideR[kM] = qn[V];
+        load_c<T, V>(rq[(U + 1) % 6], rowptr(rhs, t));
       }
     }
     const int io = t - TS;
     if (io >= ra && io <= rb) store_c<T, V>(pn + at(g, io, j0), carry, j0, jlo, jhi);
+  };
+
+  for (int t = t0; t <= t1; t += 6) {
+    sub(IC<0>{}, t);
+    if (t + 1 > t1) break;
+    sub(IC<1>{}, t + 1);
+    if (t + 2 > t1) break;
+    sub(IC<2>{}, t + 2);
+    if (t + 3 > t1) break;
+    sub(IC<3>{}, t + 3);
+    if (t + 4 > t1) break;
+    sub(IC<4>{}, t + 4);
+    if (t + 5 > t1) break;
+    sub(IC<5>{}, t + 5);
   }
 }
 
@@ -885,7 +933,7 @@ __device__ __forceinline__ void fct_face(T w, T dt, T Fm, T Fp, T& L, T& a) {
 //   x-sweep: flux = fl_L - fr_L + 0 - 0 ; y-sweep: flux = 0 - 0 + fb_L - ft_L  (same value: Llo - Lhi)
 template <typename T>
 __device__ __forceinline__ T fct_ftd(const Consts<T>& c, T F, T Llo, T Lhi, T dv) {
-  T ftd = (F + (Llo - Lhi) * c.dy / c.dxdy) * c.dx * c.dy / dv;
+  T ftd = (F + div_by_const<T, true>((Llo - Lhi) * c.dy, c.dxdy, c.inv_dxdy)) * c.dx * c.dy / dv;
   if (ftd > (T)1. || ftd < 0) ftd = var3((T)0, (T)1, ftd);
   return ftd;
 }
@@ -911,7 +959,7 @@ __device__ __forceinline__ T fct_climit(T a, T rp_m, T rm_m, T rp_p, T rm_p) {
 // stage D (:376-382 / :442-448) + optional fused post_process_f (:452-455)
 template <typename T, bool POST>
 __device__ __forceinline__ T fct_final(const Consts<T>& c, T ftd, T alo, T clo, T ahi, T chi, T dv) {
-  T f = ftd - ((ahi * chi - alo * clo) / (c.dy)) * c.dx * c.dy / dv;
+  T f = ftd - div_by_const<T, true>(ahi * chi - alo * clo, c.dy, c.inv_dy) * c.dx * c.dy / dv;
   f = var3((T)0, (T)1, f);
   if (POST) f = var3(f, (T)0, (T)1);
   return f;
@@ -948,10 +996,20 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
     return base + at(g, rc, j0);
   };
   load_c<T, V>(F1, rowptr(F, ra - 3));
+  T Fnx[V], unx[V];  // rows r of F and u, prefetched one iteration ahead
+  load_c<T, V>(Fnx, rowptr(F, ra - 2));
+  load_c<T, V>(unx, rowptr(u, ra - 2));
   for (int r = ra - 2; r <= rb + 3; ++r) {
     T Fr[V], ur[V];
-    load_c<T, V>(Fr, rowptr(F, r));
-    load_c<T, V>(ur, rowptr(u, r));
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      Fr[q] = Fnx[q];
+      ur[q] = unx[q];
+    }
+    if (r < rb + 3) {
+      load_c<T, V>(Fnx, rowptr(F, r + 1));
+      load_c<T, V>(unx, rowptr(u, r + 1));
+    }
     T out[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
@@ -1002,15 +1060,25 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
   const int jlo = c0 + 4 > 1 ? c0 + 4 : 1;
   const int jhi = c0 + W - 5 < ny ? c0 + W - 5 : ny;
   size_t o = at(g, ra, j0);
+  T Fnx[V], vnx[V];  // next row, prefetched
+  load_c<T, V>(Fnx, F + o);
+  load_c<T, V>(vnx, v + o);
   for (int i = ra; i <= rb; ++i, o += g.pitch) {
     T Fz[V], vz[V];
-    load_c<T, V>(Fz, F + o);
-    load_c<T, V>(vz, v + o);
-    const T Fl = __shfl_up(Fz[V - 1], 1, 64);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      Fz[q] = Fnx[q];
+      vz[q] = vnx[q];
+    }
+    if (i < rb) {
+      load_c<T, V>(Fnx, F + o + g.pitch);
+      load_c<T, V>(vnx, v + o + g.pitch);
+    }
+    const T Fl = lane_up(Fz[V - 1]);
     T L[V], a[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) fct_face<T>(vz[q], c.dt, q == 0 ? Fl : Fz[q - 1], Fz[q], L[q], a[q]);
-    const T Ln = __shfl_down(L[0], 1, 64), an_ = __shfl_down(a[0], 1, 64), vn = __shfl_down(vz[0], 1, 64);
+    const T Ln = lane_dn(L[0]), an_ = lane_dn(a[0]), vn = lane_dn(vz[0]);
     T td[V], dv[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
@@ -1018,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
       dv[q] = c.dxdy - c.dtdx * ((q == V - 1 ? vn : vz[q + 1]) - vz[q]);
       td[q] = (j >= 1 && j <= ny) ? fct_ftd<T>(c, Fz[q], L[q], q == V - 1 ? Ln : L[q + 1], dv[q]) : (T)0;
     }
-    const T tl = __shfl_up(td[V - 1], 1, 64), tr = __shfl_down(td[0], 1, 64);
+    const T tl = lane_up(td[V - 1]), tr = lane_dn(td[0]);
     T rp[V], rm[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
@@ -1028,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
         fct_ratios<T>(c, td[q], q == 0 ? tl : td[q - 1], q == V - 1 ? tr : td[q + 1], a[q],
                       q == V - 1 ? an_ : a[q + 1], rp[q], rm[q]);
     }
-    const T rpl = __shfl_up(rp[V - 1], 1, 64), rml = __shfl_up(rm[V - 1], 1, 64);
+    const T rpl = lane_up(rp[V - 1]), rml = lane_up(rm[V - 1]);
     T cy[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
@@ -1037,7 +1105,7 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
                   ? fct_climit<T>(a[q], q == 0 ? rpl : rp[q - 1], q == 0 ? rml : rm[q - 1], rp[q], rm[q])
                   : (T)0;
     }
-    const T cn = __shfl_down(cy[0], 1, 64);
+    const T cn = lane_dn(cy[0]);
     T out[V];
 #pragma unroll
     for (int q = 0; q < V; ++q)
