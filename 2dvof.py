@@ -49,8 +49,7 @@ def main():
     gy = sim.eng.get_param("gy")
     Lx, Ly = sim.eng.get_param("Lx"), sim.eng.get_param("Ly")
 
-    print(f'>>> A VOF solver written in Taichi; Press q to exit.'.replace('Taichi', 'HIP for MI355X')
-          .replace('Press q', 'Press Ctrl-C'))
+    print(f'>>> A VOF solver written in HIP for MI355X; Press Ctrl-C to exit.')
     print(f'>>> Grid resolution: {nx} x {ny}, dt = {dt:4.2e}')
     print(f'>>> Density ratio: {rho_l / rho_g : 4.2f}, gravity : {gy : 4.2f}, sigma : {sim.sigma[None] : 4.2f}')
     print(f'>>> Viscosity ratio: {nu_l / nu_g : 4.2f}')

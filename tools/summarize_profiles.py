@@ -67,15 +67,14 @@ def main():
                     hbm = (2 * v["fetch_kib"] + v["write_kib"]) * 1024
                     f.write("| %s | %.0f | %.0f | %.1f | %.2f |\n" % (k, v["fetch_kib"], v["write_kib"], hbm / 1e6,
                                                                      hbm / (a.nx * a.ny * esz)))
-        jk = [k for k in agg if k.startswith("vof::k_jacobi") and "fetch_kib" in agg[k]]
-        if jk:
-            k = max(jk, key=lambda q: agg[q]["launches_fetch_kib"])
-            v = agg[k]
-            json.dump({"nx": a.nx, "ny": a.ny, "dtype": a.dtype, "kernel": k, "tag": a.tag,
-                       "fetch_size_kib": v["fetch_kib"], "write_size_kib": v["write_kib"],
-                       "hbm_bytes_per_launch": (2 * v["fetch_kib"] + v["write_kib"]) * 1024,
-                       "rule": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes"},
-                      open(os.path.join(out, "jacobi_pmc.json"), "w"), indent=1)
+        rec = {"nx": a.nx, "ny": a.ny, "dtype": a.dtype, "tag": a.tag, "hbm_bytes_per_launch": {},
+               "rule": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes", "kernels": {}}
+        for k, v in agg.items():
+            if "fetch_kib" in v and "write_kib" in v and "k_jacobi" in k:
+                key = "tb" if "k_jacobi_tb" in k else "single"
+                rec["hbm_bytes_per_launch"][key] = (2 * v["fetch_kib"] + v["write_kib"]) * 1024
+                rec["kernels"][key] = {"name": k, "fetch_size_kib": v["fetch_kib"], "write_size_kib": v["write_kib"]}
+        json.dump(rec, open(os.path.join(out, "jacobi_pmc.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
