@@ -105,6 +105,11 @@ int vof_post_process_f(vof2d_handle h);             /* :452-455 */
  * (istep += 1 first; 10 Jacobi sweeps; x/y sweep alternation), using the fused
  * kernel schedule.  rho/nu/kappa scratch is not materialised. */
 int vof_step(vof2d_handle h, int64_t nsteps);
+/* The same step split at the points where a field becomes final, for drivers that overlap the
+ * halo exchange with compute (vof2d/strips.py): phase 0 = predictor + pressure solve (p final),
+ * phase 1 = update_uv + set_BC (u, v final), phase 2 = VOF transport + set_BC (F final).
+ * Must be called in the order 0, 1, 2; phase 0 increments istep. */
+int vof_step_phase(vof2d_handle h, int32_t phase);
 int vof_get_istep(vof2d_handle h, int64_t* istep);
 int vof_set_istep(vof2d_handle h, int64_t istep);
 

@@ -101,6 +101,7 @@ struct vof2d_ctx {
   grid_f64 g64;
   grid_f32 g32;
   int64_t istep;
+  int next_phase;
   char err[256];
 };
 
@@ -212,6 +213,31 @@ int ovof_step(vof2d_handle h, int64_t nsteps) {
     ovof_solve_VOF_rudman(h, h->istep);
     ovof_post_process_f(h);
     ovof_set_BC(h);
+  }
+  return VOF_OK;
+}
+/* The step cut at the points where p / u,v / F become final, with each field's boundary condition
+ * applied once right after (the schedule of the HIP library's vof_step_phase, include/vof2d.h).
+ * Test double for the overlapped halo exchange; ovof_step above stays the literal main loop. */
+int ovof_step_phase(vof2d_handle h, int32_t phase) {
+  if (!h || phase < 0 || phase > 2) return VOF_EINVAL;
+  if (phase != h->next_phase) return VOF_ESTATE;
+  h->next_phase = (phase + 1) % 3;
+  if (phase == 0) {
+    h->istep += 1;
+    ovof_cal_nu_rho(h);
+    ovof_get_normal_young(h);
+    ovof_advect_upwind(h);
+    ovof_solve_p_jacobi(h, h->d.jacobi_iters);
+    DISPATCH(h, set_BC_mask, 4);
+  } else if (phase == 1) {
+    ovof_update_uv(h);
+    DISPATCH(h, set_BC_mask, 1 | 2 | 8);
+  } else {
+    ovof_solve_VOF_rudman(h, h->istep);
+    /* post_process_f on the interior (on ghosts it is dead: the F boundary condition follows) */
+    ovof_post_process_f(h);
+    DISPATCH(h, set_BC_mask, 2);
   }
   return VOF_OK;
 }

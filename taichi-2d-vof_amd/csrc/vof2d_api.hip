@@ -107,7 +107,9 @@ struct vof2d_ctx {
   int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
   int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = 64)
   int fuse_momentum = 1;
-  hipGraphExec_t gexec[2] = {nullptr, nullptr};  // [istep parity]
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
+  hipGraphExec_t gphase[4] = {nullptr, nullptr, nullptr, nullptr};  // phase 0, phase 1, phase 2 odd / even
+  int next_phase = 0;
   char err[512];
 };
 
@@ -167,11 +169,11 @@ struct L {
     hipLaunchKernelGGL(k_init_F<T>, grid, dim3(256), 0, h->stream, h->g, C(h), F_<T>(h, fF), F_<T>(h, fF2), ic,
                        h->d.Lx, h->d.Ly, (int)(h->d.coord_cast_f32 || h->d.dtype == VOF_F32));
   }
-  template <bool STORED>
+  template <int MASK>
   static void set_bc(vof2d_ctx* h) {
     const int nr = h->g.row_hi - h->g.row_lo + 1;
     const int n = nr > h->g.ny + 2 ? nr : h->g.ny + 2;
-    hipLaunchKernelGGL((k_set_bc<T, STORED>), dim3((n + 255) / 256), dim3(256), 0, h->stream, h->g, F_<T>(h, fU),
+    hipLaunchKernelGGL((k_set_bc<T, MASK>), dim3((n + 255) / 256), dim3(256), 0, h->stream, h->g, F_<T>(h, fU),
                        F_<T>(h, fV), F_<T>(h, fF), F_<T>(h, fF2), F_<T>(h, fP), F_<T>(h, fRHO));
   }
   static void nu_rho(vof2d_ctx* h) {
@@ -307,32 +309,51 @@ void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
   if (cur != fP) copy_interior<T>(h, fPT, fP);
 }
 
-// the fused per-step schedule, 2dvof.py:506-528 (DESIGN.md "schedule")
+// The fused per-step schedule, 2dvof.py:506-528 (DESIGN.md "schedule"), in three phases so a
+// multi-GPU driver can ship each field's halo as soon as the field is final for the step:
+//   phase 0: predictor + pressure solve     -> p final
+//   phase 1: velocity correction + set_BC   -> u, v final
+//   phase 2: VOF transport + set_BC         -> F final
+// The reference applies the full set_BC three times per step (:518, :525, :528).  Here each field
+// gets its boundary condition once, as soon as it is final for the step -- p after the sweeps,
+// u / v (and F, whose ghosts the sweeps read) after the correction, F after the transport:
+//   * :518 only rewrites ghosts that :525 rewrites again before anything reads them (p ghosts are
+//     read by the Jacobi stencil, but always multiplied by a zero coefficient);
+//   * u, v, p do not change after :525, so :528 rewrites identical values for them.
+// After every phase the ghost cells hold exactly what the reference's calls leave there, and an
+// in-flight halo receive of a field never overlaps a kernel that writes the same field.
+template <typename T>
+void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep) {
+  if (phase == 0) {
+    // cal_nu_rho (:513) is folded into its consumers: rho/nu = f(F[i,j]) recomputed per cell
+    if (h->fuse_momentum) {
+      // :514, :517 and the (sweep-invariant, BC-independent) rhs of :239-241 in one pass
+      L<T>::momentum(h);
+    } else {
+      L<T>::normals(h);                     // :514 loop 1
+      L<T>::kappa(h);                       // :514 loop 2
+      L<T>::template predictor<false>(h);   // :517
+      L<T>::template rhs<false>(h);         // :521-522, rhs part (iteration invariant)
+    }
+    jacobi_n<T>(h, h->d.jacobi_iters, false);  // :521-522
+    L<T>::template set_bc<BC_P>(h);         // p part of :525 / :528
+  } else if (phase == 1) {
+    L<T>::template correct<false>(h);       // :524
+    L<T>::template set_bc<BC_UV | BC_F>(h); // u, v, F parts of :525 (F: also what :518 did at step 1)
+  } else {
+    if (istep % 2 == 0) {                   // :526, :312-318; post_process_f (:527) fused into the 2nd sweep
+      sweep_y<T, false>(h);
+      sweep_x<T, true>(h);
+    } else {
+      sweep_x<T, false>(h);
+      sweep_y<T, true>(h);
+    }
+    L<T>::template set_bc<BC_F>(h);         // F part of :528
+  }
+}
 template <typename T>
 void enqueue_step(vof2d_ctx* h, int64_t istep) {
-  // cal_nu_rho (:513) is folded into its consumers: rho/nu = f(F[i,j]) recomputed per cell
-  if (h->fuse_momentum) {
-    // :514, :517 and the (sweep-invariant, BC-independent) rhs of :239-241 in one pass
-    L<T>::momentum(h);
-    L<T>::template set_bc<false>(h);      // :518
-  } else {
-    L<T>::normals(h);                     // :514 loop 1
-    L<T>::kappa(h);                       // :514 loop 2
-    L<T>::template predictor<false>(h);   // :517
-    L<T>::template set_bc<false>(h);      // :518
-    L<T>::template rhs<false>(h);         // :521-522, rhs part (iteration invariant)
-  }
-  jacobi_n<T>(h, h->d.jacobi_iters, false);  // :521-522
-  L<T>::template correct<false>(h);       // :524
-  L<T>::template set_bc<false>(h);        // :525
-  if (istep % 2 == 0) {                   // :526, :312-318; post_process_f (:527) fused into the 2nd sweep
-    sweep_y<T, false>(h);
-    sweep_x<T, true>(h);
-  } else {
-    sweep_x<T, false>(h);
-    sweep_y<T, true>(h);
-  }
-  L<T>::template set_bc<false>(h);        // :528
+  for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep);
 }
 
 int ensure_ok(vof2d_ctx* h) {
@@ -365,6 +386,8 @@ int copy_rows_host(vof2d_ctx* h, int id, int g0, int g1, void* host, size_t nbyt
 void destroy_graphs(vof2d_ctx* h) {
   for (int k = 0; k < 2; ++k)
     if (h->gexec[k]) { (void)hipGraphExecDestroy(h->gexec[k]); h->gexec[k] = nullptr; }
+  for (int k = 0; k < 4; ++k)
+    if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }
 }
 
 }  // namespace
@@ -473,7 +496,7 @@ int vof_set_init_F(vof2d_handle h, int32_t ic) {
 }
 int vof_set_BC(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
-  DISPATCH_T(h, L<double>::set_bc<true>(h), L<float>::set_bc<true>(h));
+  DISPATCH_T(h, (L<double>::set_bc<BC_ALL | BC_RHO>(h)), (L<float>::set_bc<BC_ALL | BC_RHO>(h)));
   return ensure_ok(h);
 }
 int vof_cal_nu_rho(vof2d_handle h) {
@@ -533,6 +556,7 @@ int vof_post_process_f(vof2d_handle h) {
 int vof_step(vof2d_handle h, int64_t nsteps) {
   if (!h) return VOF_EINVAL;
   if (nsteps < 0) return fail(h, VOF_EINVAL, "nsteps must be >= 0");
+  if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
   const bool use_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
   for (int64_t s = 0; s < nsteps; ++s) {
     h->istep += 1;
@@ -558,6 +582,33 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       if (rc) return rc;
     }
   }
+  return VOF_OK;
+}
+int vof_step_phase(vof2d_handle h, int32_t phase) {
+  if (!h) return VOF_EINVAL;
+  if (phase < 0 || phase > 2) return fail(h, VOF_EINVAL, "phase must be 0, 1 or 2");
+  if (phase != h->next_phase) return fail(h, VOF_ESTATE, "vof_step_phase must be called in the order 0, 1, 2");
+  if (phase == 0) h->istep += 1;
+  h->next_phase = (phase + 1) % 3;
+  const bool use_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
+  if (!use_graph) {
+    DISPATCH_T(h, enqueue_phase<double>(h, phase, h->istep), enqueue_phase<float>(h, phase, h->istep));
+    return ensure_ok(h);
+  }
+  const int slot = phase < 2 ? phase : 2 + (int)(h->istep & 1);
+  if (!h->gphase[slot]) {
+    hipGraph_t graph = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    DISPATCH_T(h, enqueue_phase<double>(h, phase, h->istep), enqueue_phase<float>(h, phase, h->istep));
+    HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
+    hipError_t e = hipGraphInstantiate(&h->gphase[slot], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+      snprintf(h->err, sizeof(h->err), "hipGraphInstantiate: %s", hipGetErrorString(e));
+      return VOF_EHIP;
+    }
+  }
+  HIPCHK(h, hipGraphLaunch(h->gphase[slot], h->stream));
   return VOF_OK;
 }
 int vof_get_istep(vof2d_handle h, int64_t* istep) {

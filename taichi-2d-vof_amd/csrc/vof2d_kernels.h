@@ -181,9 +181,13 @@ __global__ __launch_bounds__(256) void k_init_F(Geom g, Consts<T> c, T* __restri
 // loop 1 skips the cells loop 2 overwrites, so one launch reproduces the
 // sequential "loop 1 then loop 2" result (corners take loop-2 values, S11).
 // F ghosts are mirrored into the sweep twin F2 (see k_fct_*).
-template <typename T, bool STORED>
+// MASK selects the fields (BC_UV | BC_F | BC_P | BC_RHO): the fused step applies each field's
+// boundary condition once, right after the field is final (DESIGN.md "schedule").
+enum : int { BC_UV = 1, BC_F = 2, BC_P = 4, BC_RHO = 8, BC_ALL = 7 };
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void k_set_bc(Geom g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ F,
                                                  T* __restrict__ F2, T* __restrict__ p, T* __restrict__ rho) {
+  constexpr bool UV = MASK & BC_UV, DF = MASK & BC_F, DP = MASK & BC_P, STORED = MASK & BC_RHO;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ny = g.ny, nx = g.nx;
   // loop 1: row i
@@ -192,18 +196,24 @@ __global__ __launch_bounds__(256) void k_set_bc(Geom g, T* __restrict__ u, T* __
     const bool wall_row = (g.wall_lo && i == 1) || (g.wall_hi && i == nx + 1);    // u zeroed by loop 2
     const bool ghost_row = (g.wall_lo && i == 0) || (g.wall_hi && i == nx + 1);   // F,p,v,rho from loop 2
     const size_t a0 = at(g, i, 0), a1 = at(g, i, 1), b0 = at(g, i, ny), b1 = at(g, i, ny + 1);
-    if (!wall_row) {
+    if (UV && !wall_row) {
       u[a0] = u[a1];
       u[b1] = u[b0];
     }
     if (!ghost_row) {
-      v[a1] = (T)0;
-      v[b1] = (T)0;
-      T f0 = F[a1], f1 = F[b0];
-      F[a0] = f0; F[b1] = f1;
-      F2[a0] = f0; F2[b1] = f1;
-      p[a0] = p[a1];
-      p[b1] = p[b0];
+      if (UV) {
+        v[a1] = (T)0;
+        v[b1] = (T)0;
+      }
+      if (DF) {
+        T f0 = F[a1], f1 = F[b0];
+        F[a0] = f0; F[b1] = f1;
+        F2[a0] = f0; F2[b1] = f1;
+      }
+      if (DP) {
+        p[a0] = p[a1];
+        p[b1] = p[b0];
+      }
       if (STORED) {
         rho[a0] = rho[a1];
         rho[b1] = rho[b0];
@@ -216,21 +226,29 @@ __global__ __launch_bounds__(256) void k_set_bc(Geom g, T* __restrict__ u, T* __
     const int jj = j == 0 ? 1 : (j == ny + 1 ? ny : j);  // value loop 1 leaves at column j
     const bool vz = (j == 1 || j == ny + 1);             // loop 1 zeroed v there
     if (g.wall_lo) {
-      u[at(g, 1, j)] = (T)0;
-      v[at(g, 0, j)] = vz ? (T)0 : v[at(g, 1, j)];
-      T f = F[at(g, 1, jj)];
-      F[at(g, 0, j)] = f;
-      F2[at(g, 0, j)] = f;
-      p[at(g, 0, j)] = p[at(g, 1, jj)];
+      if (UV) {
+        u[at(g, 1, j)] = (T)0;
+        v[at(g, 0, j)] = vz ? (T)0 : v[at(g, 1, j)];
+      }
+      if (DF) {
+        T f = F[at(g, 1, jj)];
+        F[at(g, 0, j)] = f;
+        F2[at(g, 0, j)] = f;
+      }
+      if (DP) p[at(g, 0, j)] = p[at(g, 1, jj)];
       if (STORED) rho[at(g, 0, j)] = rho[at(g, 1, jj)];
     }
     if (g.wall_hi) {
-      u[at(g, nx + 1, j)] = (T)0;
-      v[at(g, nx + 1, j)] = vz ? (T)0 : v[at(g, nx, j)];
-      T f = F[at(g, nx, jj)];
-      F[at(g, nx + 1, j)] = f;
-      F2[at(g, nx + 1, j)] = f;
-      p[at(g, nx + 1, j)] = p[at(g, nx, jj)];
+      if (UV) {
+        u[at(g, nx + 1, j)] = (T)0;
+        v[at(g, nx + 1, j)] = vz ? (T)0 : v[at(g, nx, j)];
+      }
+      if (DF) {
+        T f = F[at(g, nx, jj)];
+        F[at(g, nx + 1, j)] = f;
+        F2[at(g, nx + 1, j)] = f;
+      }
+      if (DP) p[at(g, nx + 1, j)] = p[at(g, nx, jj)];
       if (STORED) rho[at(g, nx + 1, j)] = rho[at(g, nx, jj)];
     }
   }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "solve_VOF_rudman": (C.c_int, [H, _i64]),
     "post_process_f": (C.c_int, [H]),
     "step": (C.c_int, [H, _i64]),
+    "step_phase": (C.c_int, [H, _i32]),
     "get_istep": (C.c_int, [H, C.POINTER(_i64)]),
     "set_istep": (C.c_int, [H, _i64]),
     "solve_p_residual": (C.c_int, [H, _dbl, _i32, _i32, C.POINTER(_i32), C.POINTER(_dbl)]),

@@ -128,6 +128,9 @@ class Engine:
     def step(self, nsteps=1):
         self._ck(self.api.step(self._h, int(nsteps)), "step")
 
+    def step_phase(self, phase):
+        self._ck(self.api.step_phase(self._h, int(phase)), "step_phase")
+
     @property
     def istep(self):
         v = C.c_int64()

@@ -114,33 +114,58 @@ class StripSolver:
         return t[g0 - self.rows[0]: g1 - self.rows[0] + 1]
 
     # -- exchange ----------------------------------------------------------------------
-    def exchange(self):
-        """Refresh the halo rows of F, u, v, p from both neighbours (one batched P2P group)."""
-        if self.world == 1:
-            return
+    def _exchange_async(self, fields):
+        """Post the halo send/recvs of `fields` with both neighbours as one batched P2P group;
+        returns the outstanding works.  RCCL orders the transfers after everything already
+        enqueued on the solver's stream and runs them on its own stream."""
         dist, W = self.dist, self.halo
         lo, hi = self.own
         ops = []
-        if self.rank > 0:  # lower neighbour owns rows < lo
-            for f in EXCHANGED:
+        for f in fields:
+            if self.rank > 0:  # lower neighbour owns rows < lo
                 ops.append(dist.P2POp(dist.isend, self._rows_view(f, lo, lo + W - 1), self.rank - 1))
                 ops.append(dist.P2POp(dist.irecv, self._rows_view(f, lo - W, lo - 1), self.rank - 1))
-        if self.rank < self.world - 1:
-            for f in EXCHANGED:
+            if self.rank < self.world - 1:
                 ops.append(dist.P2POp(dist.isend, self._rows_view(f, hi - W + 1, hi), self.rank + 1))
                 ops.append(dist.P2POp(dist.irecv, self._rows_view(f, hi + 1, hi + W), self.rank + 1))
-        for w in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def exchange(self, fields=EXCHANGED):
+        """Refresh the halo rows of `fields` from both neighbours and wait for them."""
+        if self.world == 1:
+            return
+        for w in self._exchange_async(fields):
             w.wait()
 
     def _ctx(self):
         import contextlib
         return self.torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()
 
-    def step(self, nsteps=1):
+    def step(self, nsteps=1, overlap=True):
+        """nsteps time steps.  With overlap (default) each field's halo is shipped as soon as the
+        field is final for the step -- p after the pressure solve, u and v after the velocity
+        correction, F after the transport -- so only F's exchange (a quarter of the bytes) is
+        exposed; the rest runs on RCCL's stream under the remaining kernels.  A halo row that is
+        still being read by a later kernel of the same step while it is received is either being
+        overwritten with the identical value (rows inside this rank's still-valid region) or lies
+        in the invalid fringe, so owned rows are unaffected; no kernel of a later phase writes a
+        field whose exchange is in flight (DESIGN.md "strips")."""
         with self._ctx():
             for _ in range(nsteps):
-                self.eng.step(1)
-                self.exchange()
+                if self.world == 1:
+                    self.eng.step(1)
+                elif not overlap:
+                    self.eng.step(1)
+                    self.exchange()
+                else:
+                    self.eng.step_phase(0)
+                    works = self._exchange_async(("p",))
+                    self.eng.step_phase(1)
+                    works += self._exchange_async(("u", "v"))
+                    self.eng.step_phase(2)
+                    works += self._exchange_async(("F",))
+                    for w in works:
+                        w.wait()
 
     def solve_p_residual(self, tol, max_iters, check_every=10):
         """Extension: Jacobi until the global max|p_new - p| <= tol (all-reduce MAX over ranks).
@@ -158,24 +183,10 @@ class StripSolver:
                     t = torch.tensor([res], dtype=torch.float64, device=self.device if self.on_gpu else "cpu")
                     self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
                     res = float(t.item())
-                    self._exchange_fields(("p",))
+                    self.exchange(("p",))
                 if res <= tol:
                     break
         return done, res
-
-    def _exchange_fields(self, fields):
-        dist, W = self.dist, self.halo
-        lo, hi = self.own
-        ops = []
-        for f in fields:
-            if self.rank > 0:
-                ops.append(dist.P2POp(dist.isend, self._rows_view(f, lo, lo + W - 1), self.rank - 1))
-                ops.append(dist.P2POp(dist.irecv, self._rows_view(f, lo - W, lo - 1), self.rank - 1))
-            if self.rank < self.world - 1:
-                ops.append(dist.P2POp(dist.isend, self._rows_view(f, hi - W + 1, hi), self.rank + 1))
-                ops.append(dist.P2POp(dist.irecv, self._rows_view(f, hi + 1, hi + W), self.rank + 1))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
 
     def sync(self):
         self.eng.sync()

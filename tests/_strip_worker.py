@@ -18,7 +18,7 @@ def oracle_api():
     return _abi.bind(lib, "ovof_", optional=("timer_start", "timer_stop", "time_jacobi"))
 
 
-def run(rank, world, port, nx, ny, ic, dtype, steps, outdir):
+def run(rank, world, port, nx, ny, ic, dtype, steps, outdir, overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       OMP_NUM_THREADS="1")
     import torch.distributed as dist
@@ -26,7 +26,7 @@ def run(rank, world, port, nx, ny, ic, dtype, steps, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         s = StripSolver(nx, ny, dtype, ic=ic, rank=rank, world=world, api=oracle_api(), dist=dist)
-        s.step(steps)
+        s.step(steps, overlap=overlap)
         fields = {f: s.gather(f) for f in ("F", "u", "v", "p")}
         it, res = s.solve_p_residual(1e-9, 40, 10)
         p_after = s.gather("p")

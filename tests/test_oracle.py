@@ -132,3 +132,18 @@ def test_halo_narrower_than_required_breaks_invariance(oracle_api):
             b.copy_rows_from(a, f, mid + 1 - W, mid)
         ok = ok and same(a.get("p", (1, mid)), full.get("p", (1, mid)))
     assert not ok
+
+
+def test_phased_step_equals_literal_main_loop(oracle_api):
+    """ovof_step_phase (per-field boundary schedule, used under the overlapped halo exchange)
+    leaves every field, ghosts included, exactly as the literal main loop of ovof_step does."""
+    for ic, dtype in ((1, "f64"), (2, "f64"), (3, "f32")):
+        a = engine(oracle_api, 40, 28, dtype, "f32", ic=ic)
+        b = engine(oracle_api, 40, 28, dtype, "f32", ic=ic)
+        for step in range(1, 16):
+            a.step(1)
+            for ph in (0, 1, 2):
+                b.step_phase(ph)
+            for f in ("F", "u", "v", "p", "u_star", "v_star"):
+                assert same(a.get(f), b.get(f)), "ic %d step %d %s" % (ic, step, diff_report(a.get(f), b.get(f), f))
+        assert a.istep == b.istep == 15

@@ -207,3 +207,46 @@ def test_baseline_size_4096_matches_oracle_and_properties(hip_api, oracle_api):
     assert same(F[:, 0], F[:, 1]) and same(F[0, :], F[1, :]) and same(F[n + 1, :], F[n, :])
     u, v = a.get("u"), a.get("v")
     assert not u[1].any() and not u[n + 1].any() and not v[:, 1].any() and not v[:, n + 1].any()
+
+
+def test_phased_step_and_state_errors(hip_api, oracle_api):
+    """vof_step_phase 0/1/2 == vof_step == the oracle's literal main loop; wrong order is refused."""
+    from vof2d.engine import VofError
+    a = engine(hip_api, 70, 50, "f64", "f32", ic=2)
+    b = engine(hip_api, 70, 50, "f64", "f32", ic=2)
+    ref = engine(oracle_api, 70, 50, "f64", "f32", ic=2)
+    for step in range(1, 9):
+        a.step(1)
+        ref.step(1)
+        for ph in (0, 1, 2):
+            b.step_phase(ph)
+        assert_fields_same(a, b, STATE + SCRATCH, ctx="phased vs fused, step %d" % step)
+        assert_fields_same(a, ref, STATE, ctx="fused vs oracle, step %d" % step)
+    with pytest.raises(VofError):
+        b.step_phase(1)
+    b.step_phase(0)
+    with pytest.raises(VofError):
+        b.step(1)
+
+
+def test_phased_strips_on_one_gpu(hip_api):
+    """Two strips advanced phase by phase with each field's halo copied as soon as it is final
+    (the schedule StripSolver runs over RCCL) equal the single domain on their owned rows."""
+    nx, ny, W = 96, 48, halo_rows(10)
+    mid = nx // 2
+    full = engine(hip_api, nx, ny, "f64", "f32", ic=3)
+    a = engine(hip_api, nx, ny, "f64", "f32", ic=3, rows=(0, mid + W), own=(1, mid))
+    b = engine(hip_api, nx, ny, "f64", "f32", ic=3, rows=(mid + 1 - W, nx + 1), own=(mid + 1, nx))
+
+    def swap(fields):
+        for f in fields:
+            a.copy_rows_from(b, f, mid + 1, mid + W)
+            b.copy_rows_from(a, f, mid + 1 - W, mid)
+
+    for step in range(1, 21):
+        full.step(1)
+        for ph, fields in ((0, ("p",)), (1, ("u", "v")), (2, ("F",))):
+            a.step_phase(ph); b.step_phase(ph)
+            swap(fields)
+        assert_fields_same(a, full, STATE, rows=(0, mid), ctx="step %d strip a" % step)
+        assert_fields_same(b, full, STATE, rows=(mid + 1, nx + 1), ctx="step %d strip b" % step)

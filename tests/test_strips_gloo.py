@@ -32,13 +32,18 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("nx,ny,ic,dtype,world", [(72, 40, 1, "f64", 2), (66, 24, 2, "f32", 2), (96, 20, 3, "f64", 3)])
-def test_two_rank_strips_equal_single_domain(oracle_api, tmp_path, nx, ny, ic, dtype, world):
+@pytest.mark.parametrize("nx,ny,ic,dtype,world,overlap", [
+    (72, 40, 1, "f64", 2, True), (72, 40, 1, "f64", 2, False), (66, 24, 2, "f32", 2, True),
+    (96, 20, 3, "f64", 3, True), (128, 33, 1, "f64", 4, True)])
+def test_strips_equal_single_domain(oracle_api, tmp_path, nx, ny, ic, dtype, world, overlap):
+    """overlap=True: the phased step with each field's halo sent as soon as it is final, the
+    transfers running concurrently (gloo threads here, RCCL's stream on the GPU) with the rest of
+    the step; overlap=False: one exchange after the whole step.  Both must equal the single domain."""
     import torch.multiprocessing as mp
     import _strip_worker
     steps = 12
-    mp.spawn(_strip_worker.run, args=(world, _free_port(), nx, ny, ic, dtype, steps, str(tmp_path)), nprocs=world,
-             join=True)
+    mp.spawn(_strip_worker.run, args=(world, _free_port(), nx, ny, ic, dtype, steps, str(tmp_path), overlap),
+             nprocs=world, join=True)
     z = np.load(tmp_path / "strips.npz")
     ref = engine(oracle_api, nx, ny, dtype, "f32", ic=ic)
     ref.step(steps)
