@@ -446,6 +446,23 @@ __global__ __launch_bounds__(256) void k_predictor(Geom g, Consts<T> c, const T*
 // which invalidates 2 columns on each tile side (tiles overlap by 2*H, H = 2 rounded up to V).
 // Never-written entries read as 0 exactly like the zero-initialised reference fields (S5):
 // mx/my/kappa outside the interior, u* on wall faces, v* at j = 1 and j = ny+1.
+// first-order upwind difference (:210-211, :223-224): pos ? (c - m) : (p - c).  Selecting the
+// operands instead of the results performs the identical subtraction with half the arithmetic.
+template <typename T>
+__device__ __forceinline__ T upwind_diff(bool pos, T c, T m, T p) {
+  const T a = pos ? c : p, b = pos ? m : c;
+  return a - b;
+}
+// t / d for d > 0 (a sum of two densities).  Away from the interface the surface-tension force t
+// is an exact zero and 0 / d = 0 with the sign of t, so the division is skipped (wave-level
+// branch); otherwise it is the IEEE division.
+template <typename T>
+__device__ __forceinline__ T div_or_zero(T t, T d) {
+  T r = t;
+  if (t != (T)0) r = t / d;
+  return r;
+}
+
 template <typename T>
 __device__ __forceinline__ void normals_cell(const Consts<T>& c, T Fmm, T Fm0, T Fmp, T F0m, T F00, T F0p, T Fpm,
                                              T Fp0, T Fpp, T& ox, T& oy) {
@@ -468,6 +485,15 @@ __device__ __forceinline__ void normals_cell(const Consts<T>& c, T Fmm, T Fm0, T
     ox = mxsum / magnitude;
     oy = mysum / magnitude;
   }
+}
+
+// all V+2 values of a lane's row window are equal
+template <typename T, int V>
+__device__ __forceinline__ bool row_flat(const Row<T, V>& w) {
+  bool f = w.l == w.c[0] && w.c[V - 1] == w.r;
+#pragma unroll
+  for (int q = 1; q < V; ++q) f = f && w.c[q] == w.c[0];
+  return f;
 }
 
 template <typename T, int V>
@@ -514,6 +540,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   load_row<T, V>(v2, rowptr(v, r0 - 2));
 #pragma unroll
   for (int q = 0; q < V; ++q) F3c[q] = mx2[q] = mx3[q] = my2[q] = k3[q] = us3[q] = vs3[q] = rho3[q] = (T)0;
+  bool flat2 = row_flat<T, V>(F2), flat1 = row_flat<T, V>(F1), flat0;  // rows r-2, r-1, r all-equal tests
   Row<T, V> Fn, un, vn;  // prefetched: F row r, u / v row r-1
   load_row<T, V>(Fn, rowptr(F, r0));
   load_row<T, V>(un, rowptr(u, r0 - 1));
@@ -528,13 +555,23 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
     // ---- N: normals of row r-1 (:285-306)
     const bool okN = (r - 1) >= ilo && (r - 1) <= ihi;
     T mx1[V], my1[V];
+    // Away from the interface all 3 x (V+2) values of F a lane sees are equal; every corner
+    // difference of :287-294 is then an exact zero and (mx, my) = (0, 0).  When that holds for the
+    // whole wave the stage is skipped (flatF[k] caches the per-row test, one row is new per step).
+    flat0 = row_flat<T, V>(F0);
+    const bool flat = flat2 && flat1 && flat0 && F2.c[0] == F1.c[0] && F1.c[0] == F0.c[0];
+    if (__all(flat)) {
 #pragma unroll
-    for (int q = 0; q < V; ++q) {
-      T ox, oy;
-      normals_cell<T>(c, left_of(F2, q), F2.c[q], right_of(F2, q), left_of(F1, q), F1.c[q], right_of(F1, q),
-                      left_of(F0, q), F0.c[q], right_of(F0, q), ox, oy);
-      mx1[q] = (okN && dom[q]) ? ox : (T)0;
-      my1[q] = (okN && dom[q]) ? oy : (T)0;
+      for (int q = 0; q < V; ++q) mx1[q] = my1[q] = (T)0;
+    } else {
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        T ox, oy;
+        normals_cell<T>(c, left_of(F2, q), F2.c[q], right_of(F2, q), left_of(F1, q), F1.c[q], right_of(F1, q),
+                        left_of(F0, q), F0.c[q], right_of(F0, q), ox, oy);
+        mx1[q] = (okN && dom[q]) ? ox : (T)0;
+        my1[q] = (okN && dom[q]) ? oy : (T)0;
+      }
     }
     // ---- K: kappa of row r-2 (:307-309)
     const bool okK = (r - 2) >= ilo && (r - 2) <= ihi;
@@ -566,21 +603,21 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
       T ou, ov;
       {
         T v_here = (T)0.25 * (vm0 + vmp + v00 + v0p);
-        T dudx = u00 > 0 ? (u00 - um0) * dxi : (up0 - u00) * dxi;
-        T dudy = v_here > 0 ? (u00 - u0m) * dyi : (u0p - u00) * dyi;
+        T dudx = upwind_diff<T>(u00 > 0, u00, um0, up0) * dxi;      // (u00-um0)*dxi or (up0-u00)*dxi
+        T dudy = upwind_diff<T>(v_here > 0, u00, u0m, u0p) * dyi;
         T kappa_ave = (k00 + km0) / (T)2.0;
         T fx_kappa = div_by_const<T, true>(-c.sigma * (F00 - Fm0) * kappa_ave, c.dx, c.inv_dx);
         ou = (u00 + dt * (nu00 * (um0 - (T)2 * u00 + up0) * dxi2 + nu00 * (u0m - (T)2 * u00 + u0p) * dyi2 -
-                          u00 * dudx - v_here * dudy + c.gx + fx_kappa * (T)2 / (rho00 + rhom0)));
+                          u00 * dudx - v_here * dudy + c.gx + div_or_zero<T>(fx_kappa * (T)2, rho00 + rhom0)));
       }
       {
         T u_here = (T)0.25 * (u0m + u00 + upm + up0);
-        T dvdx = u_here > 0 ? (v00 - vm0) * dxi : (vp0 - v00) * dxi;
-        T dvdy = v00 > 0 ? (v00 - v0m) * dyi : (v0p - v00) * dyi;
+        T dvdx = upwind_diff<T>(u_here > 0, v00, vm0, vp0) * dxi;
+        T dvdy = upwind_diff<T>(v00 > 0, v00, v0m, v0p) * dyi;
         T kappa_ave = (k00 + k0m) / (T)2.0;
         T fy_kappa = div_by_const<T, true>(-c.sigma * (F00 - F0m) * kappa_ave, c.dy, c.inv_dy);
         ov = (v00 + dt * (nu00 * (vm0 - (T)2 * v00 + vp0) * dxi2 + nu00 * (v0m - (T)2 * v00 + v0p) * dyi2 -
-                          u_here * dvdx - v00 * dvdy + c.gy + fy_kappa * (T)2 / (rho00 + rho0m)));
+                          u_here * dvdx - v00 * dvdy + c.gy + div_or_zero<T>(fy_kappa * (T)2, rho00 + rho0m)));
       }
       const int j = j0 + q;
       us2[q] = (okP && i >= 2 && dom[q]) ? ou : (T)0;           // u* exists on i in [2, nx]
@@ -613,6 +650,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
       rho3[q] = rho2[q];
     }
     F2 = F1; F1 = F0;
+    flat2 = flat1; flat1 = flat0;
     u3 = u2; u2 = u1;
     v3 = v2; v2 = v1;
   }
@@ -1014,6 +1052,7 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
     return base + at(g, rc, j0);
   };
   load_c<T, V>(F1, rowptr(F, ra - 3));
+  int zrows = 0;
   T Fnx[V], unx[V];  // rows r of F and u, prefetched one iteration ahead
   load_c<T, V>(Fnx, rowptr(F, ra - 2));
   load_c<T, V>(unx, rowptr(u, ra - 2));
@@ -1029,6 +1068,26 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
       load_c<T, V>(unx, rowptr(u, r + 1));
     }
     T out[V];
+    // Where F is identically 0 (the gas side of the interface) every flux, F~, limiter and the new
+    // F are exact zeros.  zrows counts the consecutive newest rows in which every lane of the wave
+    // loaded only zeros (wave-uniform); once the whole 7-row dependency window F[r-6..r] is zero
+    // the pipeline is bypassed: only dv (which depends on u alone) keeps being tracked.
+    bool rz = true;
+#pragma unroll
+    for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
+    zrows = __all(rz) ? zrows + 1 : 0;
+    if (zrows >= 7) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const T dv1 = c.dxdy - c.dtdy * (ur[q] - u1[q]);
+        out[q] = (T)0;
+        F1[q] = Fr[q]; u1[q] = ur[q]; L1[q] = (T)0;
+        a3[q] = a2[q] = a1[q] = (T)0;
+        t3[q] = t2[q] = (T)0;
+        d3[q] = d2[q]; d2[q] = dv1;
+        rp3[q] = rm3[q] = c3[q] = (T)0;
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       // S1: face r
@@ -1052,6 +1111,7 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
       t3[q] = t2[q]; t2[q] = tn;
       d3[q] = d2[q]; d2[q] = dv1;
       rp3[q] = rp2; rm3[q] = rm2; c3[q] = c2;
+    }
     }
     const int io = r - 3;
     if (io >= ra && io <= rb) store_c<T, V>(Fn + at(g, io, j0), out, j0, 1, g.ny);
@@ -1091,6 +1151,18 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
     if (i < rb) {
       load_c<T, V>(Fnx, F + o + g.pitch);
       load_c<T, V>(vnx, v + o + g.pitch);
+    }
+    {  // F identically 0 over the wave's whole row segment: every output of the segment is 0
+      bool rz = true;
+#pragma unroll
+      for (int q = 0; q < V; ++q) rz = rz && Fz[q] == (T)0;
+      if (__all(rz)) {
+        T zero[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) zero[q] = (T)0;
+        store_c<T, V>(Fn + o, zero, j0, jlo, jhi);
+        continue;
+      }
     }
     const T Fl = lane_up(Fz[V - 1]);
     T L[V], a[V];
