@@ -139,17 +139,19 @@ int field_id(const char* name) {
 
 template <typename T> T* F_(vof2d_ctx* h, int id) { return reinterpret_cast<T*>(h->fld[id]); }
 
-// rows per wave chunk: enough waves to fill 256 CUs several times over, but
-// long enough chunks that the 2 halo rows of a 3-row stencil stay a small
-// fraction of the traffic.
+// Rows per wave chunk.  Every marching kernel trades lead-in / halo rows per chunk against the
+// number of waves; with few cells the critical path of one wave (rows it marches sequentially,
+// each a dependent load) dominates, so chunks shrink until ~16 waves per CU are in flight.
+int chunk_rows(const vof2d_ctx* h, int ntiles, int rmin, int rmax) {
+  const long rows = h->g.ihi - h->g.ilo + 1;
+  long R = rows * ntiles / 4096;
+  if (R < rmin) R = rmin;
+  if (R > rmax) R = rmax;
+  return (int)R;
+}
 int pick_rows(const vof2d_ctx* h, int ntiles) {
   if (h->rows_override > 0) return h->rows_override;
-  const int rows = h->g.ihi - h->g.ilo + 1;
-  long waves_at_1 = (long)rows * ntiles;
-  int R = (int)(waves_at_1 / 4096);
-  if (R < 4) R = 4;
-  if (R > 32) R = 32;
-  return R;
+  return chunk_rows(h, ntiles, 2, 32);
 }
 inline unsigned blocks_for(const vof2d_ctx* h, int ntiles, int R) {
   const int rows = h->g.ihi - h->g.ilo + 1;
@@ -207,8 +209,8 @@ struct L {
     constexpr int Wt = 64 * V, Ht = ((2 + V - 1) / V) * V, ST = Wt - 2 * Ht;
     const int ntt = (h->g.ny + ST - 1) / ST;
     const int rows = h->g.ihi - h->g.ilo + 1;
-    int R = h->mom_rows > 0 ? h->mom_rows : 32;
-    while (R > 16 && (long)((rows + R - 1) / R) * ntt < 4096) R /= 2;
+    (void)rows;
+    const int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows(h, ntt, 4, 32);
     hipLaunchKernelGGL((k_momentum<T, V>), dim3(blocks_for(h, ntt, R)), dim3(256), 0, h->stream, h->g, C(h),
                        F_<T>(h, fF), F_<T>(h, fU), F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R,
                        ntt);
@@ -232,8 +234,10 @@ struct L {
     constexpr int Wt = 64 * V, Ht = ((TS - 1 + V - 1) / V) * V, ST = Wt - 2 * Ht;
     const int ntt = (h->g.ny + ST - 1) / ST;
     const int rows = h->g.ihi - h->g.ilo + 1;
-    int R = h->tb_rows > 0 ? h->tb_rows : 32;
-    while (h->tb_rows <= 0 && R > 16 && (long)((rows + R - 1) / R) * ntt < 4096) R /= 2;  // >= ~16 waves per CU
+    // 16-row chunks: 2*TS-1 lead-in rows cost ~30 % extra stage work but the kernel is bound by
+    // exposed load latency at 3 waves/SIMD, which more (shorter) waves hide better (measured)
+    const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows(h, ntt, 4, 16);
+    (void)rows;
     hipLaunchKernelGGL((k_jacobi_tb<T, V, TS>), dim3(blocks_for(h, ntt, R)), dim3(256), 0, h->stream, h->g, C(h),
                        F_<T>(h, src), F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
   }
@@ -247,7 +251,7 @@ struct L {
   // sweeps read fld[fF], write fld[fF2]; the caller swaps the two afterwards
   template <bool POST>
   static void fct_x(vof2d_ctx* h) {
-    const int R = h->fctx_rows > 0 ? h->fctx_rows : 32;
+    const int R = h->fctx_rows > 0 ? h->fctx_rows : chunk_rows(h, h->g.ntj, 4, 16);
     hipLaunchKernelGGL((k_fct_x<T, V, POST>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g,
                        C(h), F_<T>(h, fF), F_<T>(h, fU), F_<T>(h, fF2), R);
   }
