@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("-ic", type=int, default=1, choices=[1, 2, 3])
     ap.add_argument("--jacobi-sweeps-timed", type=int, default=200)
+    ap.add_argument("--jacobi-iters", type=int, default=10, help="sweeps per step (reference: 10, 2dvof.py:521)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -80,7 +81,7 @@ def cpu_baseline(nx, ny, dtype, ic, target_s):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     cores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)   # read by libgomp when the oracle library loads
-    api = _abi.bind(ctypes.CDLL(so), "ovof_", optional=("timer_start", "timer_stop", "time_jacobi"))
+    api = _abi.bind(ctypes.CDLL(so), "ovof_", optional=_abi.GPU_ONLY)
     e = Engine(api, make_desc(api, nx, ny, dtype, "f32"))
     e.set_init_F(ic)
     t0 = time.perf_counter()
@@ -116,7 +117,7 @@ def main():
         from vof2d._lib import hip_api
         from vof2d.engine import Engine, make_desc
         api = hip_api()
-        eng = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=local))
+        eng = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters))
         eng.set_init_F(a.ic)
         eng.step(a.warmup)
         eng.sync()
@@ -132,7 +133,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local)
+        solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local,
+                             jacobi_iters=a.jacobi_iters)
         eng = solver.eng
         solver.step(a.warmup)
         torch.cuda.synchronize()
@@ -148,21 +150,47 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # Jacobi kernels, timed with HIP events on the stream they are launched on (vof_time_jacobi).
-    # (1) the kernel the step really uses: k_jacobi_tb, `tb` sweeps fused per launch;
-    # (2) the plain one-sweep-per-launch kernel k_jacobi (the HBM-bound form of SURVEY 8d).
+    # Jacobi kernels.
+    # (1) the north-star kernel: k_jacobi, one sweep per launch, 3 array passes, HBM-bound.  Timed
+    #     live with one HIP event pair on the stream the kernels are launched on, around
+    #     --jacobi-sweeps-timed back-to-back launches (vof_time_jacobi).  Agrees with rocprofv3.
+    # (2) what the step actually runs: k_jacobi_tb, `tb` sweeps fused per launch (VALU-bound).  Its
+    #     duration depends on the clock state: sustained back-to-back launches (event pair, same
+    #     call) run ~20 % slower than the two launches interleaved in a real step, so the in-step
+    #     cost is also derived from wall-clock step times with and without the pressure sweeps.
     comp_rows = min(nx, eng.row_hi - 1) - max(1, eng.row_lo + 1) + 1
     sweep_bytes = 3 * esz * comp_rows * ny          # read p, read rhs, write p' per computed cell
     tb = int(eng.get_param("jacobi_tb"))
-    nt = max(tb * 2, (a.jacobi_sweeps_timed // (2 * tb)) * 2 * tb)
+    nt = max(2 * tb, a.jacobi_sweeps_timed // (2 * tb) * 2 * tb)
     ms_sweep_tb = eng.time_jacobi(nt)
     eng.set_param("jacobi_tb", 1)
     ms_sweep_1 = eng.time_jacobi(max(2, a.jacobi_sweeps_timed // 2 * 2))
     eng.set_param("jacobi_tb", tb)
     violations = eng.get_counter("courant_violations")
-    achieved_tb = sweep_bytes / (ms_sweep_tb * 1e-3) / 1e9      # algorithmic 24 B/cell/sweep rule
     achieved_1 = sweep_bytes / (ms_sweep_1 * 1e-3) / 1e9
     traffic = load_pmc_traffic(nx, ny, a.dtype) if world == 1 else {}
+    fused = {"kernel": "k_jacobi_tb", "sweeps_per_launch": tb, "bound": "valu",
+             "us_per_launch_back_to_back": 1e3 * ms_sweep_tb * tb, "us_per_sweep_back_to_back": 1e3 * ms_sweep_tb,
+             "hbm_traffic_bytes_per_launch": traffic.get("tb")}
+    if world == 1 and a.jacobi_iters > 0 and a.jacobi_iters % tb == 0:
+        # in-step cost: (step with sweeps - step without sweeps) / launches, both graph-replayed
+        from vof2d.engine import Engine as _E, make_desc as _md
+        e0 = _E(api, _md(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=0))
+        e0.set_init_F(a.ic)
+        e0.step(a.warmup)
+        e0.sync()
+        t0 = time.perf_counter()
+        e0.step(a.steps)
+        e0.sync()
+        ms0 = 1e3 * (time.perf_counter() - t0) / a.steps
+        e0.close()
+        launches = a.jacobi_iters // tb
+        us_in_step = (1e3 * elapsed / a.steps - ms0) * 1e3 / launches
+        fused.update({"us_per_launch_in_step": us_in_step, "us_per_sweep_in_step": us_in_step / tb,
+                      "ms_per_step_without_sweeps": ms0,
+                      "algorithmic_GBs_in_step": sweep_bytes * tb / (us_in_step * 1e-6) / 1e9})
+    prof = eng.profile_steps(14) if world == 1 else {}
+    kernels_us = {k: round(v[0], 2) for k, v in prof.items()}
 
     if rank == 0:
         out = {
@@ -176,31 +204,22 @@ def main():
             "vs_baseline": None,
             "dtype": a.dtype,
             "data": "synthetic (set_init_F -ic %d generated on device)" % a.ic,
-            "config": {"workload": "%dx%d -ic %d %s, 10 Jacobi sweeps/step, %s" % (
-                nx, ny, a.ic, a.dtype, "single strip" if world == 1 else
+            "config": {"workload": "%dx%d -ic %d %s, %d Jacobi sweeps/step, %s" % (
+                nx, ny, a.ic, a.dtype, a.jacobi_iters, "single strip" if world == 1 else
                 "%d row strips, %d-row deep halo, 1 RCCL P2P exchange/step" % (world, solver.halo)),
-                "nx": nx, "ny": ny, "jacobi_iters": 10,
+                "nx": nx, "ny": ny, "jacobi_iters": a.jacobi_iters,
                 "arrays_per_cell_update": ARRAYS_PER_STEP,
                 "bytes_per_cell_update_algorithmic": ARRAYS_PER_STEP * esz},
-            # dominant kernel of the step: the fused-sweep Jacobi.  achieved = algorithmic bytes
-            # (24 B x cells x sweeps in the launch) / launch time; it can exceed the HBM
-            # peak because temporal blocking keeps the intermediate sweeps in registers -- `traffic`
-            # is what really crossed HBM per launch (PMC) and hbm_frac_actual the real HBM load.
-            "roofline": {"bound": "hbm", "kernel": "k_jacobi_tb<%d sweeps/launch>" % tb,
-                         "achieved": achieved_tb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_tb / HBM_PEAK_GBS,
-                         "traffic": traffic.get("tb"),
-                         "hbm_frac_actual": (traffic["tb"] / (ms_sweep_tb * tb * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                         if traffic.get("tb") else None,
-                         "sweeps_per_launch": tb, "us_per_launch": 1e3 * ms_sweep_tb * tb,
-                         "us_per_sweep": 1e3 * ms_sweep_tb,
-                         "algorithmic_bytes_per_launch": sweep_bytes * tb},
-            # the plain single-sweep kernel: genuinely HBM-bound, the north-star ">= 60 % of peak" figure
-            "roofline_single_sweep": {"bound": "hbm", "kernel": "k_jacobi", "achieved": achieved_1,
-                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_1 / HBM_PEAK_GBS,
-                                      "traffic": traffic.get("single"), "us_per_launch": 1e3 * ms_sweep_1,
-                                      "algorithmic_bytes_per_launch": sweep_bytes},
+            # The Poisson Jacobi kernel (north star): algorithmic bytes = 3 arrays x sizeof(T) x
+            # cells per launch, duration from the HIP-event pair above; `traffic` = HBM
+            # bytes per launch from the committed rocprofv3 --pmc passes (profiles/jacobi_pmc.json).
+            "roofline": {"bound": "hbm", "kernel": "k_jacobi", "achieved": achieved_1, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved_1 / HBM_PEAK_GBS, "traffic": traffic.get("single"),
+                         "us_per_launch": 1e3 * ms_sweep_1, "algorithmic_bytes_per_launch": sweep_bytes,
+                         "launches_timed": max(2, a.jacobi_sweeps_timed // 2 * 2)},
+            "jacobi_fused": fused,
             "step_hbm_gbs_algorithmic": ARRAYS_PER_STEP * esz * nx * ny * a.steps / elapsed / 1e9,
+            "kernels_us_dispatch_start_to_stop": kernels_us,
             "courant_violations": violations,
         }
         if world == 1 and not a.no_cpu_baseline:

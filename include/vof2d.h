@@ -153,8 +153,16 @@ int vof_sync(vof2d_handle h);
 /* hipEvent pair on the handle's stream */
 int vof_timer_start(vof2d_handle h);
 int vof_timer_stop(vof2d_handle h, float* ms); /* records, synchronises, returns elapsed */
-/* n Jacobi sweeps only (no rhs build), timed with hipEvents on the handle's
- * stream; *ms_per_sweep = elapsed / n.  p is advanced by n sweeps. */
+/* Built-in in-situ profiler: nsteps steps of the fused schedule with a start/stop event pair on
+ * every dispatch (hipExtLaunchKernelGGL); per-kernel sums accumulate until vof_reset_profile.
+ * kernel names: k_momentum k_set_bc k_jacobi k_jacobi_tb k_correct k_fct_x k_fct_y (+ k_normals
+ * k_kappa k_predictor k_rhs when the momentum fusion is off).  The state advances by nsteps. */
+int vof_profile_steps(vof2d_handle h, int64_t nsteps);
+int vof_get_profile(vof2d_handle h, const char* kernel, double* avg_us, int64_t* launches);
+int vof_reset_profile(vof2d_handle h);
+/* n (even) Jacobi sweeps of the current rhs, back to back, between one hipEvent pair on the
+ * handle's stream; *ms_per_sweep = elapsed / n.  p advances by n sweeps.  Uses the kernels the
+ * step uses (k_jacobi_tb launches of `jacobi_tb` sweeps, k_jacobi when that parameter is 1). */
 int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep);
 const char* vof_last_error(vof2d_handle h);
 /* "hip-gfx950" for the product library, "cpu-oracle" for oracle/ */

@@ -5,6 +5,7 @@
 // host<->device copies behind to_numpy()/from_numpy().  No CPU compute path
 // exists here: every verb is a kernel launch.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -110,6 +111,13 @@ struct vof2d_ctx {
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
   hipGraphExec_t gphase[4] = {nullptr, nullptr, nullptr, nullptr};  // phase 0, phase 1, phase 2 odd / even
   int next_phase = 0;
+  // built-in in-situ profiler (vof_profile_steps): every launch carries a start/stop event pair
+  static constexpr int kMaxTimed = 96;
+  hipEvent_t tev[2 * kMaxTimed] = {};
+  int timed = -1;             // -1: off; otherwise launches recorded in the current batch
+  int tkid[kMaxTimed];        // kernel id of each recorded launch
+  double prof_sum_ms[16] = {};
+  long prof_cnt[16] = {};
   char err[512];
 };
 
@@ -161,6 +169,26 @@ inline unsigned blocks_for(const vof2d_ctx* h, int ntiles, int R) {
 }
 
 // ------------------------------------------------------------------ launches
+enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
+                kRhs, kOther, NKERNELS };
+const char* const kKernelNames[NKERNELS] = {"k_momentum", "k_set_bc", "k_jacobi", "k_jacobi_tb", "k_correct",
+                                            "k_fct_x", "k_fct_y", "k_normals", "k_kappa", "k_predictor", "k_rhs",
+                                            "other"};
+
+// One place through which every kernel is launched.  In profiling mode the dispatch carries its
+// own start/stop events (hipExtLaunchKernelGGL: the begin/end timestamps of the dispatch itself,
+// no extra barrier packets), otherwise it is a plain launch.
+template <typename... KArgs, typename... Args>
+void launch(vof2d_ctx* h, int kid, void (*kernel)(KArgs...), dim3 grid, size_t lds, Args... args) {
+  if (h->timed >= 0 && h->timed < vof2d_ctx::kMaxTimed) {
+    const int k = h->timed++;
+    h->tkid[k] = kid;
+    hipExtLaunchKernelGGL(kernel, grid, dim3(256), lds, h->stream, h->tev[2 * k], h->tev[2 * k + 1], 0, args...);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, h->stream, args...);
+  }
+}
+
 template <typename T>
 struct L {
   static constexpr int V = VecWidth<T>::V;
@@ -168,99 +196,93 @@ struct L {
 
   static void init_F(vof2d_ctx* h, int ic) {
     dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
-    hipLaunchKernelGGL(k_init_F<T>, grid, dim3(256), 0, h->stream, h->g, C(h), F_<T>(h, fF), F_<T>(h, fF2), ic,
-                       h->d.Lx, h->d.Ly, (int)(h->d.coord_cast_f32 || h->d.dtype == VOF_F32));
+    launch(h, kOther, k_init_F<T>, grid, 0, h->g, C(h), F_<T>(h, fF), F_<T>(h, fF2), ic, h->d.Lx, h->d.Ly,
+           (int)(h->d.coord_cast_f32 || h->d.dtype == VOF_F32));
   }
   template <int MASK>
   static void set_bc(vof2d_ctx* h) {
     const int nr = h->g.row_hi - h->g.row_lo + 1;
     const int n = nr > h->g.ny + 2 ? nr : h->g.ny + 2;
-    hipLaunchKernelGGL((k_set_bc<T, MASK>), dim3((n + 255) / 256), dim3(256), 0, h->stream, h->g, F_<T>(h, fU),
-                       F_<T>(h, fV), F_<T>(h, fF), F_<T>(h, fF2), F_<T>(h, fP), F_<T>(h, fRHO));
+    launch(h, kSetBC, k_set_bc<T, MASK>, dim3((n + 255) / 256), 0, h->g, F_<T>(h, fU), F_<T>(h, fV), F_<T>(h, fF),
+           F_<T>(h, fF2), F_<T>(h, fP), F_<T>(h, fRHO));
   }
   static void nu_rho(vof2d_ctx* h) {
     dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
-    hipLaunchKernelGGL(k_nu_rho<T>, grid, dim3(256), 0, h->stream, h->g, C(h), F_<T>(h, fF), F_<T>(h, fRHO),
-                       F_<T>(h, fNU));
+    launch(h, kOther, k_nu_rho<T>, grid, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fRHO), F_<T>(h, fNU));
   }
   static void post(vof2d_ctx* h) {
     dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
-    hipLaunchKernelGGL(k_post<T>, grid, dim3(256), 0, h->stream, h->g, F_<T>(h, fF), F_<T>(h, fF2));
+    launch(h, kOther, k_post<T>, grid, 0, h->g, F_<T>(h, fF), F_<T>(h, fF2));
   }
   static void normals(vof2d_ctx* h) {
     const int R = pick_rows(h, h->g.ntj);
-    hipLaunchKernelGGL((k_normals<T, V>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g, C(h),
-                       F_<T>(h, fF), F_<T>(h, fMX), F_<T>(h, fMY), R);
+    launch(h, kNormals, k_normals<T, V>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+           F_<T>(h, fMX), F_<T>(h, fMY), R);
   }
   static void kappa(vof2d_ctx* h) {
     const int R = pick_rows(h, h->g.ntj);
-    hipLaunchKernelGGL((k_kappa<T, V>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g, C(h),
-                       F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fKAPPA), R);
+    launch(h, kKappa, k_kappa<T, V>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h), (const T*)F_<T>(h, fMX),
+           (const T*)F_<T>(h, fMY), F_<T>(h, fKAPPA), R);
   }
   template <bool STORED>
   static void predictor(vof2d_ctx* h) {
     const int R = pick_rows(h, h->g.ntj);
-    hipLaunchKernelGGL((k_predictor<T, V, STORED>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream,
-                       h->g, C(h), F_<T>(h, fU), F_<T>(h, fV), F_<T>(h, fKAPPA), F_<T>(h, fF), F_<T>(h, fRHO),
-                       F_<T>(h, fNU), F_<T>(h, fUS), F_<T>(h, fVS), R);
+    launch(h, kPredictor, k_predictor<T, V, STORED>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), (const T*)F_<T>(h, fKAPPA), (const T*)F_<T>(h, fF),
+           (const T*)F_<T>(h, fRHO), (const T*)F_<T>(h, fNU), F_<T>(h, fUS), F_<T>(h, fVS), R);
   }
   // fused normals + kappa + predictor + rhs (vof_step only)
   static void momentum(vof2d_ctx* h) {
     constexpr int Wt = 64 * V, Ht = ((2 + V - 1) / V) * V, ST = Wt - 2 * Ht;
     const int ntt = (h->g.ny + ST - 1) / ST;
-    const int rows = h->g.ihi - h->g.ilo + 1;
-    (void)rows;
     const int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows(h, ntt, 4, 32);
-    hipLaunchKernelGGL((k_momentum<T, V>), dim3(blocks_for(h, ntt, R)), dim3(256), 0, h->stream, h->g, C(h),
-                       F_<T>(h, fF), F_<T>(h, fU), F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R,
-                       ntt);
+    launch(h, kMomentum, k_momentum<T, V>, dim3(blocks_for(h, ntt, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+           (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt);
   }
   template <bool STORED>
   static void rhs(vof2d_ctx* h) {
     const int R = pick_rows(h, h->g.ntj);
-    hipLaunchKernelGGL((k_rhs<T, V, STORED>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g,
-                       C(h), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fF), F_<T>(h, fRHO), F_<T>(h, fRHS), R);
+    launch(h, kRhs, k_rhs<T, V, STORED>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h), (const T*)F_<T>(h, fUS),
+           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fRHO), F_<T>(h, fRHS), R);
   }
   // one sweep src -> dst
   template <bool RESID>
   static void jacobi(vof2d_ctx* h, int src, int dst) {
     const int R = pick_rows(h, h->g.ntj);
-    hipLaunchKernelGGL((k_jacobi<T, V, 2, RESID>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream,
-                       h->g, C(h), F_<T>(h, src), F_<T>(h, fRHS), F_<T>(h, dst), R, h->d_courant + 1);
+    launch(h, kJacobi, k_jacobi<T, V, 2, RESID>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, h->d_courant + 1);
   }
   // TS sweeps src -> dst in one launch
   template <int TS>
   static void jacobi_tb(vof2d_ctx* h, int src, int dst) {
     constexpr int Wt = 64 * V, Ht = ((TS - 1 + V - 1) / V) * V, ST = Wt - 2 * Ht;
     const int ntt = (h->g.ny + ST - 1) / ST;
-    const int rows = h->g.ihi - h->g.ilo + 1;
-    // 16-row chunks: 2*TS-1 lead-in rows cost ~30 % extra stage work but the kernel is bound by
+    // short chunks: 2*TS-1 lead-in rows cost ~30 % extra stage work, but the kernel is bound by
     // exposed load latency at 3 waves/SIMD, which more (shorter) waves hide better (measured)
     const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows(h, ntt, 4, 16);
-    (void)rows;
-    hipLaunchKernelGGL((k_jacobi_tb<T, V, TS>), dim3(blocks_for(h, ntt, R)), dim3(256), 0, h->stream, h->g, C(h),
-                       F_<T>(h, src), F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
+    launch(h, kJacobiTB, k_jacobi_tb<T, V, TS>, dim3(blocks_for(h, ntt, R)), 0, h->g, C(h), (const T*)F_<T>(h, src),
+           (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
   }
   template <bool STORED>
   static void correct(vof2d_ctx* h) {
     const int R = pick_rows(h, h->g.ntj);
-    hipLaunchKernelGGL((k_correct<T, V, STORED>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g,
-                       C(h), F_<T>(h, fP), F_<T>(h, fF), F_<T>(h, fRHO), F_<T>(h, fUS), F_<T>(h, fVS),
-                       F_<T>(h, fU), F_<T>(h, fV), R, h->d_courant);
+    launch(h, kCorrect, k_correct<T, V, STORED>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fP), (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fRHO), (const T*)F_<T>(h, fUS),
+           (const T*)F_<T>(h, fVS), F_<T>(h, fU), F_<T>(h, fV), R, h->d_courant);
   }
   // sweeps read fld[fF], write fld[fF2]; the caller swaps the two afterwards
   template <bool POST>
   static void fct_x(vof2d_ctx* h) {
     const int R = h->fctx_rows > 0 ? h->fctx_rows : chunk_rows(h, h->g.ntj, 4, 16);
-    hipLaunchKernelGGL((k_fct_x<T, V, POST>), dim3(blocks_for(h, h->g.ntj, R)), dim3(256), 0, h->stream, h->g,
-                       C(h), F_<T>(h, fF), F_<T>(h, fU), F_<T>(h, fF2), R);
+    launch(h, kFctX, k_fct_x<T, V, POST>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+           (const T*)F_<T>(h, fU), F_<T>(h, fF2), R);
   }
   template <bool POST>
   static void fct_y(vof2d_ctx* h) {
     int R = pick_rows(h, h->nty);
     if (h->rows_override <= 0 && R > 16) R = 16;
-    hipLaunchKernelGGL((k_fct_y<T, V, POST>), dim3(blocks_for(h, h->nty, R)), dim3(256), 0, h->stream, h->g, C(h),
-                       F_<T>(h, fF), F_<T>(h, fV), F_<T>(h, fF2), R, h->nty);
+    launch(h, kFctY, k_fct_y<T, V, POST>, dim3(blocks_for(h, h->nty, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+           (const T*)F_<T>(h, fV), F_<T>(h, fF2), R, h->nty);
   }
 };
 
@@ -483,6 +505,8 @@ int vof_destroy(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   destroy_graphs(h);
+  for (int k = 0; k < 2 * vof2d_ctx::kMaxTimed; ++k)
+    if (h->tev[k]) (void)hipEventDestroy(h->tev[k]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->d_courant) (void)hipFree(h->d_courant);
@@ -790,9 +814,63 @@ int vof_timer_stop(vof2d_handle h, float* ms) {
   HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
   return VOF_OK;
 }
+// nsteps steps of the fused schedule launched eagerly with a start/stop event pair on every
+// dispatch; durations accumulate per kernel (vof_get_profile).  Steps are enqueued in batches
+// without host synchronisation in between (an idle GPU drops its clocks).
+int vof_profile_steps(vof2d_handle h, int64_t nsteps) {
+  if (!h) return VOF_EINVAL;
+  if (nsteps < 0) return fail(h, VOF_EINVAL, "nsteps must be >= 0");
+  if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
+  for (int k = 0; k < 2 * vof2d_ctx::kMaxTimed; ++k)
+    if (!h->tev[k]) HIPCHK(h, hipEventCreate(&h->tev[k]));
+  const int per_step = 16 + h->d.jacobi_iters;  // upper bound of launches in one step
+  int64_t done = 0;
+  while (done < nsteps) {
+    h->timed = 0;
+    int batch = 0;
+    while (done + batch < nsteps && h->timed + per_step <= vof2d_ctx::kMaxTimed) {
+      h->istep += 1;
+      DISPATCH_T(h, enqueue_step<double>(h, h->istep), enqueue_step<float>(h, h->istep));
+      ++batch;
+    }
+    const int launches = h->timed;
+    h->timed = -1;
+    if (batch == 0) return fail(h, VOF_ESTATE, "a step has more launches than the profiling event pool");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // Dispatch start -> stop.  A dispatch's start stamp is taken when the command processor picks
+    // the packet up, while the predecessor's last waves are still draining, so for kernels that
+    // follow a long-tailed kernel the figure includes that overlap (the per-step sum can exceed the
+    // wall time by ~5 %); it is a diagnostic breakdown, rocprofv3 gives exclusive times.
+    for (int k = 0; k < launches; ++k) {
+      float ms = 0.f;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->tev[2 * k], h->tev[2 * k + 1]));
+      h->prof_sum_ms[h->tkid[k]] += ms;
+      h->prof_cnt[h->tkid[k]] += 1;
+    }
+    done += batch;
+  }
+  return ensure_ok(h);
+}
+int vof_get_profile(vof2d_handle h, const char* kernel, double* avg_us, int64_t* launches) {
+  if (!h || !kernel) return VOF_EINVAL;
+  for (int k = 0; k < NKERNELS; ++k)
+    if (!strcmp(kernel, kKernelNames[k])) {
+      if (avg_us) *avg_us = h->prof_cnt[k] ? 1e3 * h->prof_sum_ms[k] / (double)h->prof_cnt[k] : 0.0;
+      if (launches) *launches = h->prof_cnt[k];
+      return VOF_OK;
+    }
+  return fail(h, VOF_EINVAL, "unknown kernel name");
+}
+int vof_reset_profile(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  for (int k = 0; k < NKERNELS; ++k) { h->prof_sum_ms[k] = 0.0; h->prof_cnt[k] = 0; }
+  return VOF_OK;
+}
 int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep) {
   if (!h || !ms_per_sweep) return VOF_EINVAL;
   if (n < 2 || (n & 1)) return fail(h, VOF_EINVAL, "n must be even and >= 2");
+  if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
+  // one hipEvent pair on the handle's stream around n back-to-back sweeps of the current rhs
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   DISPATCH_T(h, jacobi_n<double>(h, n, false), jacobi_n<float>(h, n, false));
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));

@@ -81,9 +81,16 @@ SIGNATURES = {
     "timer_start": (C.c_int, [H]),
     "timer_stop": (C.c_int, [H, C.POINTER(C.c_float)]),
     "time_jacobi": (C.c_int, [H, _i32, C.POINTER(C.c_float)]),
+    "profile_steps": (C.c_int, [H, _i64]),
+    "get_profile": (C.c_int, [H, _str, C.POINTER(_dbl), C.POINTER(_i64)]),
+    "reset_profile": (C.c_int, [H]),
     "last_error": (C.c_char_p, [H]),
     "backend": (C.c_char_p, []),
 }
+
+
+# entry points that only the GPU library implements (timing / profiling on a HIP stream)
+GPU_ONLY = ("timer_start", "timer_stop", "time_jacobi", "profile_steps", "get_profile", "reset_profile")
 
 
 class Api:

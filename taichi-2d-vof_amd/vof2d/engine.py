@@ -208,6 +208,20 @@ class Engine:
         self._ck(self.api.timer_stop(self._h, C.byref(ms)), "timer_stop")
         return ms.value
 
+    def profile_steps(self, nsteps, reset=True):
+        """In-situ per-kernel profile of nsteps fused steps: {kernel: (avg_us, launches)}."""
+        if reset:
+            self._ck(self.api.reset_profile(self._h), "reset_profile")
+        self._ck(self.api.profile_steps(self._h, int(nsteps)), "profile_steps")
+        out = {}
+        for k in ("k_momentum", "k_set_bc", "k_jacobi", "k_jacobi_tb", "k_correct", "k_fct_x", "k_fct_y",
+                  "k_normals", "k_kappa", "k_predictor", "k_rhs"):
+            us, n = C.c_double(), C.c_int64()
+            self._ck(self.api.get_profile(self._h, k.encode(), C.byref(us), C.byref(n)), "get_profile")
+            if n.value:
+                out[k] = (us.value, n.value)
+        return out
+
     def time_jacobi(self, n):
         ms = C.c_float()
         self._ck(self.api.time_jacobi(self._h, int(n), C.byref(ms)), "time_jacobi")

@@ -15,7 +15,7 @@ for p in (os.path.join(ROOT, "taichi-2d-vof_amd"), os.path.join(ROOT, "oracle"),
 def oracle_api():
     from vof2d import _abi
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libvof_oracle.so"))
-    return _abi.bind(lib, "ovof_", optional=("timer_start", "timer_stop", "time_jacobi"))
+    return _abi.bind(lib, "ovof_", optional=_abi.GPU_ONLY)
 
 
 def run(rank, world, port, nx, ny, ic, dtype, steps, outdir, overlap=True):

@@ -25,7 +25,7 @@ def oracle_api():
     if not os.path.exists(ORACLE_SO):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     lib = ctypes.CDLL(ORACLE_SO)
-    return _abi.bind(lib, "ovof_", optional=("timer_start", "timer_stop", "time_jacobi"))
+    return _abi.bind(lib, "ovof_", optional=_abi.GPU_ONLY)
 
 
 @pytest.fixture(scope="session")

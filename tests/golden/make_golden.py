@@ -35,7 +35,7 @@ CASES = {
 
 def main():
     api = _abi.bind(ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libvof_oracle.so")), "ovof_",
-                    optional=("timer_start", "timer_stop", "time_jacobi"))
+                    optional=_abi.GPU_ONLY)
     for name, (nx, ny, ic, dtype, cast, steps) in CASES.items():
         s = onp.new_state(nx, ny, ic, dtype=NPDT[dtype], coord_cast=cast)
         e = engine(api, nx, ny, dtype, cast, ic=ic)

@@ -28,6 +28,6 @@ for tb, rows_list in ((1, (0,)), (2, (16, 32, 64)), (5, (16, 32, 64, 128)), (10,
         e.set_param("jacobi_tb_rows", rows)
         e.solve_p_jacobi(20)
         ok = np.array_equal(e.get("p"), ref)
-        ms = e.time_jacobi(200 if tb > 1 else 100)
+        ms = e.time_jacobi(200)
         print("tb=%2d rows=%3d  same_as_single=%s  %.2f us/sweep  %.0f GB/s-equivalent (24B rule/sweep)  launch=%.1f us" % (
             tb, rows, ok, ms * 1e3, 3 * esz * n * n / (ms * 1e-3) / 1e9, ms * 1e3 * tb), flush=True)
