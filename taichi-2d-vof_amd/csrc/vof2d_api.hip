@@ -106,6 +106,7 @@ struct vof2d_ctx {
   int tb = 5;           // Jacobi sweeps fused per launch (1 = plain kernel)
   int tb_rows = 0;      // rows per wave chunk of the fused kernel (0 = heuristic)
   int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
+  int tb_general = 0;   // force the general (dx != dy) fused Jacobi kernel
   int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = 64)
   int fuse_momentum = 1;
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
@@ -255,13 +256,20 @@ struct L {
   // TS sweeps src -> dst in one launch
   template <int TS>
   static void jacobi_tb(vof2d_ctx* h, int src, int dst) {
-    constexpr int Wt = 64 * V, Ht = ((TS - 1 + V - 1) / V) * V, ST = Wt - 2 * Ht;
+    const Consts<T> cc = C(h);
+    const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;  // square cells: the product-carrying pipeline
+    constexpr int Wt = 64 * V;
+    const int Ht = ((TS - 1 + (sq ? 1 : 0) + V - 1) / V) * V, ST = Wt - 2 * Ht;  // must match the kernel
     const int ntt = (h->g.ny + ST - 1) / ST;
     // short chunks: 2*TS-1 lead-in rows cost ~30 % extra stage work, but the kernel is bound by
     // exposed load latency at 3 waves/SIMD, which more (shorter) waves hide better (measured)
     const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows(h, ntt, 4, 16);
-    launch(h, kJacobiTB, k_jacobi_tb<T, V, TS>, dim3(blocks_for(h, ntt, R)), 0, h->g, C(h), (const T*)F_<T>(h, src),
-           (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
+    if (sq)
+      launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
+    else
+      launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
   }
   template <bool STORED>
   static void correct(vof2d_ctx* h) {
@@ -468,6 +476,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   if ((ev = getenv("VOF2D_TB"))) h->tb = atoi(ev);
   if ((ev = getenv("VOF2D_TB_ROWS"))) h->tb_rows = atoi(ev);
   if ((ev = getenv("VOF2D_FCTX_ROWS"))) h->fctx_rows = atoi(ev);
+  if ((ev = getenv("VOF2D_TB_GENERAL"))) h->tb_general = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_MOMENTUM"))) h->fuse_momentum = atoi(ev);
   if ((ev = getenv("VOF2D_MOM_ROWS"))) h->mom_rows = atoi(ev);
 

@@ -773,13 +773,22 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
 // Register rotation: stage s keeps rows i-1, i, i+1 of its input in a ring of three row buffers
 // whose roles advance by one per iteration, and the rhs rows in a ring of six; the row loop is
 // unrolled by 6 with compile-time ring positions, so no value is ever moved between registers.
-template <typename T, int V, int TS>
+template <typename T, int V, int TS, bool SQ>
 __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
                                                     const T* __restrict__ rhs, T* __restrict__ pn, int R,
                                                     int ntt) {
+  // SQ (dxi2 == dyi2 bitwise, i.e. square cells): the stencil has ONE off-diagonal coefficient, so
+  // the product coef * p[i,j] is the same number in the equations of all four neighbours of (i,j).
+  // Stages 2.. then receive products instead of values -- 1 multiply per cell-sweep instead of 4
+  // -- and their numerator is b - cE - cW - cN - cS in the reference's order with bit-identical
+  // terms.  The zero coefficients of the walls (:258-261) are reproduced at the producer: rows
+  // outside [1, nx] publish 0 * value, and cells in columns outside [1, ny] carry the value 0
+  // (their reciprocal yI is 0, so div_by_const returns 0), whose product is the same exact zero.
   static_assert(TS >= 2 && TS <= 5, "rhs ring holds 6 rows");
   constexpr int W = 64 * V;
-  constexpr int H = ((TS - 1 + V - 1) / V) * V;
+  // invalid columns per tile side after TS sweeps: TS-1 from the cross-lane exchange of sweeps
+  // 2..TS, plus 1 when the first sweep also takes its j-neighbours from adjacent lanes (SQ)
+  constexpr int H = ((TS - 1 + (SQ ? 1 : 0) + V - 1) / V) * V;
   constexpr int STRIDE = W - 2 * H;
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -802,18 +811,20 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
     as_[q] = j != 1 ? c.dyi2 : (T)0.0;
     apI[q] = (T)-1.0 * (c.dxi2 + c.dxi2 + an[q] + as_[q]);  // ap of rows 1 < i < nx
     yI[q] = (T)1 / apI[q];
+    if (SQ && (j < 1 || j > ny)) yI[q] = (T)0;  // out-of-domain columns: every sweep yields the value 0
   }
   auto rowptr = [&](const T* base, int r) {
     const int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
     return base + (size_t)(rc - g.row_lo) * (size_t)pitch + (size_t)(g.col0 + j0);
   };
 
-  // ring[s][k]: input rows of stage s+1.  In the sub-iteration with phase U (t = tb + U):
+  // ring[s][k]: input rows of stage s+1 (s = 0: values of p from memory; s > 0: the previous
+  // stage's output, as products when SQ).  In the sub-iteration with phase U (t = tb + U):
   //   ring[s][(U+0)%3] = row i-1,  ring[s][(U+1)%3] = row i,  ring[s][(U+2)%3] = row i+1 (incoming)
-  // where i = t - (s+1).  For s = 0 the rows come from memory (sideL/sideR carry their j0-1 / j0+V
-  // neighbours); for s > 0 the incoming row is the output of stage s in the same sub-iteration.
-  T ring[TS][3][V], sideL[3], sideR[3];
-  T rq[6][V];  // rq[(t-1) % 6 phase] = rhs row t-1 ...: row x lives in slot (x - xbase) mod 6
+  // where i = t - (s+1).
+  T ring[TS][3][V];
+  T sideL[3], sideR[3];  // general: j0-1 / j0+V of the memory rows (unused when SQ: DPP instead)
+  T rq[6][V];  // rhs row x lives in slot (x - (t0-1)) mod 6
 #pragma unroll
   for (int s = 0; s < TS; ++s)
 #pragma unroll
@@ -827,30 +838,32 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
 
   const int t0 = ra - TS + 2, t1 = rb + TS;
   // phase 0 at t = t0: rows t0-2, t0-1, t0 of p in ring[0][0..2]; rhs row t0-1 in rq slot 0
-  // (slot of rhs row x = (x - (t0-1)) mod 6; stage s at phase U reads row t-s -> slot (U+1-s) mod 6)
+  // (stage s at phase U reads rhs row t-s -> slot (U+1-s) mod 6)
   load_c<T, V>(ring[0][0], rowptr(p, t0 - 2));
   {
     const T* q1 = rowptr(p, t0 - 1);
     load_c<T, V>(ring[0][1], q1);
-    sideL[1] = q1[-1];
-    sideR[1] = q1[V];
     const T* q2 = rowptr(p, t0);
     load_c<T, V>(ring[0][2], q2);
-    sideL[2] = q2[-1];
-    sideR[2] = q2[V];
+    if constexpr (!SQ) {
+      sideL[0] = sideR[0] = (T)0;
+      sideL[1] = q1[-1];
+      sideR[1] = q1[V];
+      sideL[2] = q2[-1];
+      sideR[2] = q2[V];
+    }
   }
-  sideL[0] = sideR[0] = (T)0;
   load_c<T, V>(rq[0], rowptr(rhs, t0 - 1));
 
   auto sub = [&](auto uc, int t) {
     constexpr int U = decltype(uc)::value;
     constexpr int kM = U % 3, kC = (U + 1) % 3, kE = (U + 2) % 3;
-    T carry[V];  // output of the previous stage = row i+1 of this stage's input
+    T carry[V];  // output (a value of p) of the previous stage = row i+1 of this stage's input
 #pragma unroll
     for (int s = 1; s <= TS; ++s) {
       const int i = t - s;
       T sl, sr;
-      if (s == 1) {
+      if (s == 1 && !SQ) {  // (SQ: sideL/sideR are never touched)
         sl = sideL[kC];
         sr = sideR[kC];
       } else {
@@ -858,11 +871,20 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
         sr = lane_dn(ring[s - 1][kC][0]);
       }
       if (s > 1) {
+        if (SQ) {  // publish the previous stage's row i+1 as products (zero coefficient outside [1, nx])
+          const T coef = (i + 1 >= 1 && i + 1 <= nx) ? c.dxi2 : (T)0.0;
 #pragma unroll
-        for (int q = 0; q < V; ++q) ring[s - 1][kE][q] = carry[q];
+          for (int q = 0; q < V; ++q) ring[s - 1][kE][q] = coef * carry[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < V; ++q) ring[s - 1][kE][q] = carry[q];
+        }
       }
       // lead-in: stage s first matters at row ra-(TS-s), i.e. from t = ra-TS+2s on (wave-uniform)
       if (s > 1 && t < ra - TS + 2 * s) continue;
+      // Rows outside [ilo, ihi] and columns outside [1, ny] are computed like any other cell:
+      // their values are finite and only ever enter a valid cell multiplied by a zero
+      // coefficient (aw/ae at the walls, as/an at j = 1 / ny) or sit in the invalid fringe.
       const bool edge = (i == 1) || (i == nx);
       const T ae = i != nx ? c.dxi2 : (T)0.0;
       const T aw = i != 1 ? c.dxi2 : (T)0.0;
@@ -871,10 +893,16 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
       for (int q = 0; q < V; ++q) {
         const T N = q == V - 1 ? sr : ring[s - 1][kC][q + 1];
         const T S = q == 0 ? sl : ring[s - 1][kC][q - 1];
-        const T num = rq[slot][q] - ae * ring[s - 1][kE][q] - aw * ring[s - 1][kM][q] - an[q] * N - as_[q] * S;
+        T num;
+        if (SQ && s > 1)  // inputs of stages 2.. are products; stage 1 reads values of p from memory
+          num = rq[slot][q] - ring[s - 1][kE][q] - ring[s - 1][kM][q] - N - S;
+        else
+          num = rq[slot][q] - ae * ring[s - 1][kE][q] - aw * ring[s - 1][kM][q] - an[q] * N - as_[q] * S;
         if (edge) {  // wave-uniform: first / last interior row has its own ap
           const T ap = (T)-1.0 * (ae + aw + an[q] + as_[q]);
-          carry[q] = num / ap;
+          T o = num / ap;
+          if (SQ && ((j0 + q) < 1 || (j0 + q) > ny)) o = (T)0;  // same zero the interior rows produce
+          carry[q] = o;
         } else {
           carry[q] = div_by_const<T>(num, apI[q], yI[q]);
         }
@@ -883,8 +911,10 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
         // ring[0][kM] (row t-2) is dead now: prefetch row t+1 into it; rhs row t into the free slot
         const T* qn = rowptr(p, t + 1);
         load_c<T, V>(ring[0][kM], qn);
-        sideL[kM] = qn[-1];
-        sideR[kM] = qn[V];
+        if constexpr (!SQ) {
+          sideL[kM] = qn[-1];
+          sideR[kM] = qn[V];
+        }
         load_c<T, V>(rq[(U + 1) % 6], rowptr(rhs, t));
       }
     }
