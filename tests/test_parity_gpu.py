@@ -296,3 +296,35 @@ def test_residual_terminated_solve_converges(hip_api, oracle_api):
     assert_fields_same(a, b, ("p",), ctx="after 1010 sweeps")
     it, res = a.solve_p_residual(hist[-1] * 0.5, 4000, 100)
     assert res <= hist[-1] * 0.5 and it % 100 == 0 and it < 4000
+
+
+def test_baseline_8192_eight_strips_on_one_gpu(hip_api):
+    """BASELINE configs[3] geometry (8192^2 fp64, 8 row strips of 1024 rows + 16-row halos) emulated
+    on one GPU with the partition helpers StripSolver uses and the phased, per-field exchange
+    schedule: every strip equals the single-domain run on its owned rows after each step."""
+    from vof2d.strips import partition, stored_rows
+    n, world, W = 8192, 8, halo_rows(10)
+    parts = partition(n, world)
+    assert parts[0] == (1, 1024) and parts[-1] == (7169, 8192)
+    full = engine(hip_api, n, n, "f64", "f32", ic=1)
+    strips = [engine(hip_api, n, n, "f64", "f32", ic=1, rows=stored_rows(n, own, W), own=own) for own in parts]
+    assert strips[3].nrows == 1024 + 2 * W
+
+    def swap(fields):
+        for k in range(world - 1):
+            lo_s, hi_s = strips[k], strips[k + 1]
+            edge = lo_s.own_hi
+            for f in fields:
+                lo_s.copy_rows_from(hi_s, f, edge + 1, edge + W)
+                hi_s.copy_rows_from(lo_s, f, edge + 1 - W, edge)
+
+    for step in range(1, 4):
+        full.step(1)
+        for ph, fields in ((0, ("p",)), (1, ("u", "v")), (2, ("F",))):
+            for s in strips:
+                s.step_phase(ph)
+            swap(fields)
+        for s in strips[2:5:2] + [strips[0], strips[-1]]:
+            g0 = 0 if s.own_lo == 1 else s.own_lo
+            g1 = n + 1 if s.own_hi == n else s.own_hi
+            assert_fields_same(s, full, STATE, rows=(g0, g1), ctx="step %d strip %d..%d" % (step, s.own_lo, s.own_hi))
