@@ -25,8 +25,9 @@ sys.path.insert(0, os.path.join(ROOT, "taichi-2d-vof_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
 # distinct arrays read or written per cell per step by the fused schedule (DESIGN.md "schedule"):
-# k_momentum 6 (F,u,v -> u*,v*,rhs) + 2 x k_jacobi_tb 3 + k_correct 6 (p,F,u*,v* -> u,v) + 2 x k_fct 3
-ARRAYS_PER_STEP = 24
+# k_momentum 6 (F,u,v -> u*,v*,rhs) + 2 x k_jacobi_tb 3 + first FCT sweep with update_uv 7
+# (F,u*,v*,p -> F',u,v) + second FCT sweep 3;  strips (phased schedule): k_correct 6 + 2 x 3 = 24
+ARRAYS_PER_STEP = 22
 
 
 def parse():
@@ -208,8 +209,8 @@ def main():
                 nx, ny, a.ic, a.dtype, a.jacobi_iters, "single strip" if world == 1 else
                 "%d row strips, %d-row deep halo, 1 RCCL P2P exchange/step" % (world, solver.halo)),
                 "nx": nx, "ny": ny, "jacobi_iters": a.jacobi_iters,
-                "arrays_per_cell_update": ARRAYS_PER_STEP,
-                "bytes_per_cell_update_algorithmic": ARRAYS_PER_STEP * esz},
+                "arrays_per_cell_update": ARRAYS_PER_STEP if world == 1 else ARRAYS_PER_STEP + 2,
+                "bytes_per_cell_update_algorithmic": (ARRAYS_PER_STEP if world == 1 else ARRAYS_PER_STEP + 2) * esz},
             # The Poisson Jacobi kernel (north star): algorithmic bytes = 3 arrays x sizeof(T) x
             # cells per launch, duration from the HIP-event pair above; `traffic` = HBM
             # bytes per launch from the committed rocprofv3 --pmc passes (profiles/jacobi_pmc.json).
@@ -218,7 +219,7 @@ def main():
                          "us_per_launch": 1e3 * ms_sweep_1, "algorithmic_bytes_per_launch": sweep_bytes,
                          "launches_timed": max(2, a.jacobi_sweeps_timed // 2 * 2)},
             "jacobi_fused": fused,
-            "step_hbm_gbs_algorithmic": ARRAYS_PER_STEP * esz * nx * ny * a.steps / elapsed / 1e9,
+            "step_hbm_gbs_algorithmic": (ARRAYS_PER_STEP if world == 1 else ARRAYS_PER_STEP + 2) * esz * nx * ny * a.steps / elapsed / 1e9,
             "kernels_us_dispatch_start_to_stop": kernels_us,
             "courant_violations": violations,
         }

@@ -109,6 +109,7 @@ struct vof2d_ctx {
   int tb_general = 0;   // force the general (dx != dy) fused Jacobi kernel
   int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = 64)
   int fuse_momentum = 1;
+  int fuse_correct = 1; // vof_step on a full domain: update_uv inside the first FCT sweep
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
   hipGraphExec_t gphase[4] = {nullptr, nullptr, nullptr, nullptr};  // phase 0, phase 1, phase 2 odd / even
   int next_phase = 0;
@@ -278,19 +279,22 @@ struct L {
            (const T*)F_<T>(h, fP), (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fRHO), (const T*)F_<T>(h, fUS),
            (const T*)F_<T>(h, fVS), F_<T>(h, fU), F_<T>(h, fV), R, h->d_courant);
   }
-  // sweeps read fld[fF], write fld[fF2]; the caller swaps the two afterwards
-  template <bool POST>
+  // sweeps read fld[fF], write fld[fF2]; the caller swaps the two afterwards.
+  // CORR: the sweep also performs update_uv (reads u*, v*, p; writes u, v) -- see k_fct_x.
+  template <bool POST, bool CORR>
   static void fct_x(vof2d_ctx* h) {
     const int R = h->fctx_rows > 0 ? h->fctx_rows : chunk_rows(h, h->g.ntj, 4, 16);
-    launch(h, kFctX, k_fct_x<T, V, POST>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
-           (const T*)F_<T>(h, fU), F_<T>(h, fF2), R);
+    launch(h, kFctX, k_fct_x<T, V, POST, CORR>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fU), F_<T>(h, fF2), R, (const T*)F_<T>(h, fUS),
+           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant);
   }
-  template <bool POST>
+  template <bool POST, bool CORR>
   static void fct_y(vof2d_ctx* h) {
     int R = pick_rows(h, h->nty);
     if (h->rows_override <= 0 && R > 16) R = 16;
-    launch(h, kFctY, k_fct_y<T, V, POST>, dim3(blocks_for(h, h->nty, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
-           (const T*)F_<T>(h, fV), F_<T>(h, fF2), R, h->nty);
+    launch(h, kFctY, k_fct_y<T, V, POST, CORR>, dim3(blocks_for(h, h->nty, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fV), F_<T>(h, fF2), R, h->nty, (const T*)F_<T>(h, fUS),
+           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant);
   }
 };
 
@@ -300,10 +304,10 @@ void swap_F(vof2d_ctx* h) {
   h->fld[fF2] = t;
 }
 
-template <typename T, bool POST>
-void sweep_x(vof2d_ctx* h) { L<T>::template fct_x<POST>(h); swap_F(h); }
-template <typename T, bool POST>
-void sweep_y(vof2d_ctx* h) { L<T>::template fct_y<POST>(h); swap_F(h); }
+template <typename T, bool POST, bool CORR = false>
+void sweep_x(vof2d_ctx* h) { L<T>::template fct_x<POST, CORR>(h); swap_F(h); }
+template <typename T, bool POST, bool CORR = false>
+void sweep_y(vof2d_ctx* h) { L<T>::template fct_y<POST, CORR>(h); swap_F(h); }
 
 // interior copy src -> dst (only used to keep p in place for odd sweep counts)
 template <typename T>
@@ -385,9 +389,30 @@ void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep) {
     L<T>::template set_bc<BC_F>(h);         // F part of :528
   }
 }
+// vof_step: the three phases back to back -- except on a full-domain handle, where update_uv
+// (:524) is folded into whichever FCT sweep runs first (that sweep streams F anyway and needs the
+// corrected velocity): p, F, u*, v* -> u, v no longer costs its own 6-pass kernel.  u and v are
+// final before anything reads them (the second sweep, the u/v boundary condition), and p's and
+// F's boundary conditions share one launch.  The phased form keeps the separate kernel because a
+// strip driver ships u, v while the transport runs.
 template <typename T>
 void enqueue_step(vof2d_ctx* h, int64_t istep) {
-  for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep);
+  const bool full = h->g.wall_lo && h->g.wall_hi;
+  if (!(full && h->fuse_correct && h->fuse_momentum)) {
+    for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep);
+    return;
+  }
+  L<T>::momentum(h);                           // :513-517 + rhs of :239-241
+  jacobi_n<T>(h, h->d.jacobi_iters, false);    // :521-522
+  L<T>::template set_bc<BC_P | BC_F>(h);       // p part of :525/:528; F part of :518 (first step)
+  if (istep % 2 == 0) {                        // :524 + :526 (:312-318) + :527
+    sweep_y<T, false, true>(h);
+    sweep_x<T, true>(h);
+  } else {
+    sweep_x<T, false, true>(h);
+    sweep_y<T, true>(h);
+  }
+  L<T>::template set_bc<BC_UV | BC_F>(h);      // u, v part of :525; F part of :528
 }
 
 int ensure_ok(vof2d_ctx* h) {
@@ -477,6 +502,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   if ((ev = getenv("VOF2D_TB_ROWS"))) h->tb_rows = atoi(ev);
   if ((ev = getenv("VOF2D_FCTX_ROWS"))) h->fctx_rows = atoi(ev);
   if ((ev = getenv("VOF2D_TB_GENERAL"))) h->tb_general = atoi(ev);
+  if ((ev = getenv("VOF2D_FUSE_CORRECT"))) h->fuse_correct = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_MOMENTUM"))) h->fuse_momentum = atoi(ev);
   if ((ev = getenv("VOF2D_MOM_ROWS"))) h->mom_rows = atoi(ev);
 
@@ -566,12 +592,12 @@ int vof_update_uv(vof2d_handle h) {
 }
 int vof_fct_x_sweep(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
-  DISPATCH_T(h, (sweep_x<double, false>(h)), (sweep_x<float, false>(h)));
+  DISPATCH_T(h, (sweep_x<double, false, false>(h)), (sweep_x<float, false, false>(h)));
   return ensure_ok(h);
 }
 int vof_fct_y_sweep(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
-  DISPATCH_T(h, (sweep_y<double, false>(h)), (sweep_y<float, false>(h)));
+  DISPATCH_T(h, (sweep_y<double, false, false>(h)), (sweep_y<float, false, false>(h)));
   return ensure_ok(h);
 }
 int vof_solve_VOF_rudman(vof2d_handle h, int64_t istep) {
@@ -763,10 +789,11 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
     return VOF_OK;
   }
   if (!strcmp(name, "jacobi_tb") || !strcmp(name, "jacobi_tb_rows") || !strcmp(name, "momentum_rows") ||
-      !strcmp(name, "fuse_momentum")) {  // tuning knobs
+      !strcmp(name, "fuse_momentum") || !strcmp(name, "fuse_correct")) {  // tuning knobs
     if (!strcmp(name, "jacobi_tb")) h->tb = (int)value;
     else if (!strcmp(name, "jacobi_tb_rows")) h->tb_rows = (int)value;
     else if (!strcmp(name, "momentum_rows")) h->mom_rows = (int)value;
+    else if (!strcmp(name, "fuse_correct")) h->fuse_correct = (int)value;
     else h->fuse_momentum = (int)value;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     destroy_graphs(h);

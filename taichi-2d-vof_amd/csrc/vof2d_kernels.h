@@ -1057,9 +1057,25 @@ __device__ __forceinline__ T fct_final(const Consts<T>& c, T ftd, T alo, T clo, 
 // F, writes Fn (the twin); the host swaps the two pointers afterwards.
 // Zero-ghost semantics (S5): Ftd, rp, rm outside [ilo, ihi] and cx at face
 // ilo read as 0, exactly what the never-written ghost entries hold.
-template <typename T, int V, bool POST>
+// update_uv (2dvof.py:269-280) for one cell, shared by k_correct's fused forms below: the same
+// expressions in the same order.  rho_c / rho_m: density of the cell and of its lower neighbour in
+// the component's direction; pc / pm likewise for p.
+template <typename T>
+__device__ __forceinline__ T corrected_velocity(const Consts<T>& c, T star, T rho_c, T rho_m, T pc, T pm, T di) {
+  const T r = (rho_c + rho_m) * (T)0.5;
+  return star - c.dt / r * (pc - pm) * di;
+}
+
+// CORR (full-domain handles only): the sweep that runs first also performs update_uv -- it
+// computes u and v from u*, v*, p and F (rho) for the rows it streams, stores them, and feeds its
+// own component straight into the flux pipeline.  `u` is then an output (Uo) and the wall faces
+// i = 1, nx+1 carry the 0 that set_BC keeps there.
+template <typename T, int V, bool POST, bool CORR>
 __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __restrict__ F,
-                                                const T* __restrict__ u, T* __restrict__ Fn, int R) {
+                                                const T* __restrict__ u, T* __restrict__ Fn, int R,
+                                                const T* __restrict__ us, const T* __restrict__ vs,
+                                                const T* __restrict__ p, T* __restrict__ Uo, T* __restrict__ Vo,
+                                                unsigned long long* __restrict__ courant) {
   int j0, ra, rb;
   if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
   const int ilo = g.ilo, ihi = g.ihi;
@@ -1083,9 +1099,24 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
   };
   load_c<T, V>(F1, rowptr(F, ra - 3));
   int zrows = 0;
-  T Fnx[V], unx[V];  // rows r of F and u, prefetched one iteration ahead
+  T Fnx[V], unx[V];  // rows r of F and u (CORR: u*), prefetched one iteration ahead
   load_c<T, V>(Fnx, rowptr(F, ra - 2));
-  load_c<T, V>(unx, rowptr(u, ra - 2));
+  load_c<T, V>(unx, rowptr(CORR ? us : u, ra - 2));
+  // CORR state: p and rho of row r-1, prefetched p / v* / left neighbours of row r
+  T p1[V], rho1[V];
+  Row<T, V> pnx;
+  T vsnx[V], Flnx = (T)0;
+  unsigned int viol = 0;
+  if (CORR) {
+    load_c<T, V>(p1, rowptr(p, ra - 3));
+#pragma unroll
+    for (int q = 0; q < V; ++q) rho1[q] = rho_of(c, F1[q]);
+    const T* pr0 = rowptr(p, ra - 2);
+    load_c<T, V>(pnx.c, pr0);
+    pnx.l = pr0[-1];
+    load_c<T, V>(vsnx, rowptr(vs, ra - 2));
+    Flnx = rowptr(F, ra - 2)[-1];
+  }
   for (int r = ra - 2; r <= rb + 3; ++r) {
     T Fr[V], ur[V];
 #pragma unroll
@@ -1093,9 +1124,52 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
       Fr[q] = Fnx[q];
       ur[q] = unx[q];
     }
+    Row<T, V> pr;
+    T vsr[V], Flr = Flnx;
+    if (CORR) {
+      pr = pnx;
+#pragma unroll
+      for (int q = 0; q < V; ++q) vsr[q] = vsnx[q];
+    }
     if (r < rb + 3) {
       load_c<T, V>(Fnx, rowptr(F, r + 1));
-      load_c<T, V>(unx, rowptr(u, r + 1));
+      load_c<T, V>(unx, rowptr(CORR ? us : u, r + 1));
+      if (CORR) {
+        const T* prn = rowptr(p, r + 1);
+        load_c<T, V>(pnx.c, prn);
+        pnx.l = prn[-1];
+        load_c<T, V>(vsnx, rowptr(vs, r + 1));
+        Flnx = rowptr(F, r + 1)[-1];
+      }
+    }
+    if (CORR) {  // update_uv for row r (:269-280): ur currently holds u*[r]
+      T rhor[V], ov[V];
+      const T rhol = rho_of(c, Flr);
+      const bool urow = r >= 2 && r <= g.nx;   // u exists on i in [2, nx]; walls keep 0
+      const bool own = r >= ra && r <= rb;     // rows this chunk stores (and counts)
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const int j = j0 + q;
+        rhor[q] = rho_of(c, Fr[q]);
+        const T un = corrected_velocity<T>(c, ur[q], rhor[q], rho1[q], pr.c[q], p1[q], c.dxi);
+        ur[q] = urow ? un : (T)0;
+        const T rl = q == 0 ? rhol : rhor[q - 1];
+        const T pl = q == 0 ? pr.l : pr.c[q - 1];
+        ov[q] = corrected_velocity<T>(c, vsr[q], rhor[q], rl, pr.c[q], pl, c.dyi);
+        if (own && j <= g.ny && r >= g.own_lo && r <= g.own_hi) {
+          if (urow && ur[q] * c.dt > c.cfl_x) viol++;
+          if (j >= 2 && ov[q] * c.dt > c.cfl_y) viol++;
+        }
+      }
+      if (own) {
+        if (urow) store_c<T, V>(Uo + at(g, r, j0), ur, j0, 1, g.ny);
+        store_c<T, V>(Vo + at(g, r, j0), ov, j0, 2, g.ny);
+      }
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        p1[q] = pr.c[q];
+        rho1[q] = rhor[q];
+      }
     }
     T out[V];
     // Where F is identically 0 (the gas side of the interface) every flux, F~, limiter and the new
@@ -1146,15 +1220,24 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
     const int io = r - 3;
     if (io >= ra && io <= rb) store_c<T, V>(Fn + at(g, io, j0), out, j0, 1, g.ny);
   }
+  if (CORR && __any(viol != 0)) {
+    unsigned int tot = viol;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) tot += __shfl_down(tot, sft, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(courant, (unsigned long long)tot);
+  }
 }
 // 2dvof.py:385-448 fct_y_sweep, fused like k_fct_x.  The sweep direction is
 // the contiguous one, so the +-3-cell dependency is resolved across lanes with
 // wave shuffles: a wave owns 64*V consecutive cells of one row, of which the
 // inner 64*V - 8 are valid outputs (tiles overlap by 8 columns; 4 keeps the
 // 16-byte alignment of the lane accesses).  Rows are independent.
-template <typename T, int V, bool POST>
+template <typename T, int V, bool POST, bool CORR>
 __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __restrict__ F,
-                                                const T* __restrict__ v, T* __restrict__ Fn, int R, int nty) {
+                                                const T* __restrict__ v, T* __restrict__ Fn, int R, int nty,
+                                                const T* __restrict__ us, const T* __restrict__ vs,
+                                                const T* __restrict__ p, T* __restrict__ Uo, T* __restrict__ Vo,
+                                                unsigned long long* __restrict__ courant) {
   constexpr int W = 64 * V, STRIDE = W - 8;
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR: rows are wave-uniform
   const int lane = threadIdx.x & 63;
@@ -1168,19 +1251,62 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
   const int jlo = c0 + 4 > 1 ? c0 + 4 : 1;
   const int jhi = c0 + W - 5 < ny ? c0 + W - 5 : ny;
   size_t o = at(g, ra, j0);
-  T Fnx[V], vnx[V];  // next row, prefetched
+  T Fnx[V], vnx[V];  // next row (CORR: v*), prefetched
   load_c<T, V>(Fnx, F + o);
-  load_c<T, V>(vnx, v + o);
+  load_c<T, V>(vnx, (CORR ? vs : v) + o);
+  // CORR (see k_fct_x): this sweep runs first and performs update_uv for its rows
+  T p1[V], rho1[V], pnx[V], usnx[V];
+  unsigned int viol = 0;
+  if (CORR) {
+    T f1[V];
+    load_c<T, V>(p1, p + o - g.pitch);
+    load_c<T, V>(f1, F + o - g.pitch);
+#pragma unroll
+    for (int q = 0; q < V; ++q) rho1[q] = rho_of(c, f1[q]);
+    load_c<T, V>(pnx, p + o);
+    load_c<T, V>(usnx, us + o);
+  }
   for (int i = ra; i <= rb; ++i, o += g.pitch) {
-    T Fz[V], vz[V];
+    T Fz[V], vz[V], pz[V], usz[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       Fz[q] = Fnx[q];
       vz[q] = vnx[q];
+      if (CORR) {
+        pz[q] = pnx[q];
+        usz[q] = usnx[q];
+      }
     }
     if (i < rb) {
       load_c<T, V>(Fnx, F + o + g.pitch);
-      load_c<T, V>(vnx, v + o + g.pitch);
+      load_c<T, V>(vnx, (CORR ? vs : v) + o + g.pitch);
+      if (CORR) {
+        load_c<T, V>(pnx, p + o + g.pitch);
+        load_c<T, V>(usnx, us + o + g.pitch);
+      }
+    }
+    if (CORR) {  // update_uv for row i (:269-280): vz currently holds v*[i]
+      T rhoz[V], ou[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) rhoz[q] = rho_of(c, Fz[q]);
+      const T rhol = lane_up(rhoz[V - 1]), pl = lane_up(pz[V - 1]);
+      const bool own = i >= g.own_lo && i <= g.own_hi;
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const int j = j0 + q;
+        ou[q] = corrected_velocity<T>(c, usz[q], rhoz[q], rho1[q], pz[q], p1[q], c.dxi);
+        const T vn = corrected_velocity<T>(c, vz[q], rhoz[q], q == 0 ? rhol : rhoz[q - 1], pz[q],
+                                           q == 0 ? pl : pz[q - 1], c.dyi);
+        vz[q] = (j >= 2 && j <= ny) ? vn : (T)0;   // v exists on j in [2, ny]; j = 1, ny+1 keep set_BC's 0
+        if (own && j >= jlo && j <= jhi) {
+          if (i >= 2 && ou[q] * c.dt > c.cfl_x) viol++;
+          if (j >= 2 && vz[q] * c.dt > c.cfl_y) viol++;
+        }
+        p1[q] = pz[q];
+        rho1[q] = rhoz[q];
+      }
+      if (i >= 2) store_c<T, V>(Uo + o, ou, j0, jlo, jhi);
+      store_c<T, V>(Vo + o, vz, j0, jlo > 2 ? jlo : 2, jhi);
     }
     {  // F identically 0 over the wave's whole row segment: every output of the segment is 0
       bool rz = true;
@@ -1232,6 +1358,12 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
       out[q] = fct_final<T, POST>(c, td[q], a[q], cy[q], q == V - 1 ? an_ : a[q + 1], q == V - 1 ? cn : cy[q + 1],
                                   dv[q]);
     store_c<T, V>(Fn + o, out, j0, jlo, jhi);
+  }
+  if (CORR && __any(viol != 0)) {
+    unsigned int tot = viol;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) tot += __shfl_down(tot, sft, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(courant, (unsigned long long)tot);
   }
 }
 
