@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--jacobi-sweeps-timed", type=int, default=200)
     ap.add_argument("--jacobi-iters", type=int, default=10, help="sweeps per step (reference: 10, 2dvof.py:521)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the torch.distributed/StripSolver code path even with one rank (self-test)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -100,6 +102,27 @@ def cpu_baseline(nx, ny, dtype, ic, target_s):
             "ms_per_step": 1e3 * dt / n}
 
 
+class _StdoutToStderr:
+    """Route file descriptor 1 to stderr while RCCL initialises: its C-level banner would otherwise
+    land on stdout next to the one JSON line this script must print."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            ctypes.CDLL(None).fflush(None)   # C stdio buffers of the libraries
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,7 +137,8 @@ def main():
     ny = a.ny or nx
     esz = 8 if a.dtype == "f64" else 4
 
-    if world == 1:
+    dist_path = world > 1 or a.force_dist
+    if not dist_path:
         # single GPU: no torch in the process at all -- ctypes -> C ABI -> HIP
         from vof2d._lib import hip_api
         from vof2d.engine import Engine, make_desc
@@ -133,15 +157,21 @@ def main():
         import torch.distributed as dist
         from vof2d.strips import StripSolver
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:  # --force-dist without a launcher
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local,
-                             jacobi_iters=a.jacobi_iters)
-        eng = solver.eng
-        solver.step(a.warmup)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local,
+                                 jacobi_iters=a.jacobi_iters)
+            eng = solver.eng
+            solver.step(a.warmup)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         solver.step(a.steps)
         torch.cuda.synchronize()
@@ -170,11 +200,11 @@ def main():
     eng.set_param("jacobi_tb", tb)
     violations = eng.get_counter("courant_violations")
     achieved_1 = sweep_bytes / (ms_sweep_1 * 1e-3) / 1e9
-    traffic = load_pmc_traffic(nx, ny, a.dtype) if world == 1 else {}
+    traffic = load_pmc_traffic(nx, ny, a.dtype) if not dist_path else {}
     fused = {"kernel": "k_jacobi_tb", "sweeps_per_launch": tb, "bound": "valu",
              "us_per_launch_back_to_back": 1e3 * ms_sweep_tb * tb, "us_per_sweep_back_to_back": 1e3 * ms_sweep_tb,
              "hbm_traffic_bytes_per_launch": traffic.get("tb")}
-    if world == 1 and a.jacobi_iters > 0 and a.jacobi_iters % tb == 0:
+    if not dist_path and a.jacobi_iters > 0 and a.jacobi_iters % tb == 0:
         # in-step cost: (step with sweeps - step without sweeps) / launches, both graph-replayed
         from vof2d.engine import Engine as _E, make_desc as _md
         e0 = _E(api, _md(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=0))
@@ -191,7 +221,7 @@ def main():
         fused.update({"us_per_launch_in_step": us_in_step, "us_per_sweep_in_step": us_in_step / tb,
                       "ms_per_step_without_sweeps": ms0,
                       "algorithmic_GBs_in_step": sweep_bytes * tb / (us_in_step * 1e-6) / 1e9})
-    prof = eng.profile_steps(14) if world == 1 else {}
+    prof = eng.profile_steps(14) if not dist_path else {}
     kernels_us = {k: round(v[0], 2) for k, v in prof.items()}
 
     if rank == 0:
@@ -207,11 +237,12 @@ def main():
             "dtype": a.dtype,
             "data": "synthetic (set_init_F -ic %d generated on device)" % a.ic,
             "config": {"workload": "%dx%d -ic %d %s, %d Jacobi sweeps/step, %s" % (
-                nx, ny, a.ic, a.dtype, a.jacobi_iters, "single strip" if world == 1 else
-                "%d row strips, %d-row deep halo, 1 RCCL P2P exchange/step" % (world, solver.halo)),
+                nx, ny, a.ic, a.dtype, a.jacobi_iters, "single strip" if not dist_path else
+                "%d row strips, %d-row deep halo, per-field RCCL P2P exchange overlapped with the step" % (
+                    world, solver.halo)),
                 "nx": nx, "ny": ny, "jacobi_iters": a.jacobi_iters,
-                "arrays_per_cell_update": ARRAYS_PER_STEP if world == 1 else ARRAYS_PER_STEP + 2,
-                "bytes_per_cell_update_algorithmic": (ARRAYS_PER_STEP if world == 1 else ARRAYS_PER_STEP + 2) * esz},
+                "arrays_per_cell_update": ARRAYS_PER_STEP if not dist_path else ARRAYS_PER_STEP + 2,
+                "bytes_per_cell_update_algorithmic": (ARRAYS_PER_STEP if not dist_path else ARRAYS_PER_STEP + 2) * esz},
             # The Poisson Jacobi kernel (north star): algorithmic bytes = 3 arrays x sizeof(T) x
             # cells per launch, duration from the HIP-event pair above; `traffic` = HBM
             # bytes per launch from the committed rocprofv3 --pmc passes (profiles/jacobi_pmc.json).
@@ -220,14 +251,14 @@ def main():
                          "us_per_launch": 1e3 * ms_sweep_1, "algorithmic_bytes_per_launch": sweep_bytes,
                          "launches_timed": max(2, a.jacobi_sweeps_timed // 2 * 2)},
             "jacobi_fused": fused,
-            "step_hbm_gbs_algorithmic": (ARRAYS_PER_STEP if world == 1 else ARRAYS_PER_STEP + 2) * esz * nx * ny * a.steps / elapsed / 1e9,
+            "step_hbm_gbs_algorithmic": (ARRAYS_PER_STEP if not dist_path else ARRAYS_PER_STEP + 2) * esz * nx * ny * a.steps / elapsed / 1e9,
             "kernels_us_dispatch_start_to_stop": kernels_us,
             "courant_violations": violations,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if not dist_path and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, a.dtype, a.ic, a.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_path:
         import torch.distributed as dist
         dist.barrier()
         solver.close()
