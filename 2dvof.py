@@ -34,6 +34,9 @@ parser.add_argument('--verbs', action='store_true')
 parser.add_argument('--jacobi-tol', type=float, default=0.0)
 parser.add_argument('--jacobi-max', type=int, default=2000)
 parser.add_argument('--device', type=int, default=0)
+parser.add_argument('--vis', type=int, choices=[0, 1, 2, 3, 4], default=0,
+                    help='what the reference GUI would display (SPACE cycles it there, 2dvof.py:508-509): '
+                         '0 VOF, 1 u, 2 v, 3 |velocity|, 4 velocity vectors; saved as output/NNNNNN-vis.png with -s')
 
 
 def main():
@@ -82,13 +85,28 @@ def main():
             istep += n
             if (istep % nstep) == 0:  # Output data every <nstep> steps
                 warn = sim.courant_violations
-                print(f'>>> Number of steps:{istep:<5d}, Time:{istep*dt:5.2e} sec. Displaying VOF field.'
+                what = ('VOF field', 'u velocity', 'v velocity', 'velocity norm', 'velocity vectors')[args.vis]
+                print(f'>>> Number of steps:{istep:<5d}, Time:{istep*dt:5.2e} sec. Displaying {what}.'
                       + (f' [{warn} Courant warnings]' if warn else ''))
                 if SAVE_FIG:
                     import matplotlib
                     matplotlib.use('Agg')
                     import matplotlib.pyplot as plt
+                    import matplotlib.cm as cm
                     count = istep // nstep - 1
+                    # what gui.set_image(...) shows in the reference (:531-559), written to a file
+                    if args.vis == 4:
+                        V = sim.interp_velocity()
+                        sp = max(4, nx // 50)
+                        plt.figure(figsize=(5, Ly / Lx * 5))
+                        plt.axis('off')
+                        plt.quiver(V[1:nx + 1:sp, 1:ny + 1:sp, 0].T, V[1:nx + 1:sp, 1:ny + 1:sp, 1].T)
+                        plt.savefig(f'output/{count:06d}-vis.png')
+                        plt.close()
+                    else:
+                        img = (sim.get_vof_field, sim.get_u_field, sim.get_v_field, sim.get_vnorm_field)[args.vis]()
+                        cmap = (cm.Blues, cm.coolwarm, cm.coolwarm, cm.plasma)[args.vis]
+                        plt.imsave(f'output/{count:06d}-vis.png', cmap(img.transpose(1, 0)[::-1]))
                     Fnp = sim.F.to_numpy()
                     fx, fy = 5, Ly / Lx * 5
                     plt.figure(figsize=(fx, fy))

@@ -139,6 +139,13 @@ int vof_field_view(vof2d_handle h, const char* name, void** base, int64_t* pitch
  * emulation; across GPUs the exchange is RCCL send/recv on vof_field_view. */
 int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t g0, int32_t g1);
 
+/* ---- display fields (2dvof.py:458-492; full-domain handles only) ----
+ * which: "vof" get_vof_field :458-462, "u" get_u_field :465-470, "v" get_v_field :473-478,
+ * "vnorm" get_vnorm_field :481-486.  dst: the rgb_buf image, dense (2*nx, 2*ny) of the field dtype. */
+int vof_get_vis_field(vof2d_handle h, const char* which, void* dst, size_t nbytes);
+/* interp_velocity :488-492: cell-centred velocity V, dense (nx+2, ny+2, 2) of the field dtype. */
+int vof_interp_velocity(vof2d_handle h, void* dst, size_t nbytes);
+
 /* ---- scalars ---- */
 /* settable: sigma (sigma[None], :28-29).  readable: sigma dt dx dy dxi dyi
  * dxi2 dyi2 Lx Ly rho_l rho_g nu_l nu_g gx gy (Python-double values). */

@@ -305,6 +305,26 @@ int ovof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t
   return VOF_OK;
 }
 
+int ovof_get_vis_field(vof2d_handle h, const char* which, void* dst, size_t nbytes) {
+  if (!h || !which || !dst) return VOF_EINVAL;
+  if (h->d.row_lo != 0 || h->d.row_hi != h->d.nx + 1) return VOF_ESTATE;
+  int mode = !strcmp(which, "vof") ? 0 : !strcmp(which, "u") ? 1 : !strcmp(which, "v") ? 2 : !strcmp(which, "vnorm") ? 3 : -1;
+  if (mode < 0) return VOF_EINVAL;
+  size_t esz = h->d.dtype == VOF_F64 ? 8 : 4;
+  if (nbytes != (size_t)4 * h->d.nx * h->d.ny * esz) return VOF_EINVAL;
+  if (h->d.dtype == VOF_F64) vis_field_f64(&h->g64, mode, h->d.Lx, h->d.Ly, (double*)dst);
+  else vis_field_f32(&h->g32, mode, h->d.Lx, h->d.Ly, (float*)dst);
+  return VOF_OK;
+}
+int ovof_interp_velocity(vof2d_handle h, void* dst, size_t nbytes) {
+  if (!h || !dst) return VOF_EINVAL;
+  if (h->d.row_lo != 0 || h->d.row_hi != h->d.nx + 1) return VOF_ESTATE;
+  size_t esz = h->d.dtype == VOF_F64 ? 8 : 4;
+  if (nbytes != (size_t)2 * (h->d.nx + 2) * (h->d.ny + 2) * esz) return VOF_EINVAL;
+  if (h->d.dtype == VOF_F64) interp_velocity_f64(&h->g64, (double*)dst);
+  else interp_velocity_f32(&h->g32, (float*)dst);
+  return VOF_OK;
+}
 int ovof_set_param(vof2d_handle h, const char* name, double value) {
   if (!h || !name) return VOF_EINVAL;
   if (!strcmp(name, "sigma")) {

@@ -471,6 +471,37 @@ def post_process_f(s):
     s.F[...] = var(s.F, T(0), T(1))
 
 
+# 2dvof.py:458-486: rgb_buf[I] = field[I // r], r = resolution[0] // nx = 2
+def vis_field(s, which):
+    prm = s.prm
+    T = prm.T
+    nx, ny = prm.nx, prm.ny
+    a = (np.arange(2 * nx) // 2)[:, None]
+    b = (np.arange(2 * ny) // 2)[None, :]
+    if which == "vof":
+        return s.F[a, b].copy()
+    if which == "u":
+        return s.u[a, b] / T(prm.Lx / 0.2)
+    if which == "v":
+        return s.v[a, b] / T(prm.Ly / 0.2)
+    if which == "vnorm":
+        return np.sqrt(s.u[a, b] * s.u[a, b] + s.v[a, b] * s.v[a, b]) / T(prm.Ly / 0.2)
+    raise ValueError(which)
+
+
+# 2dvof.py:488-492.  The reference's loop reaches u[imax+2, j], one row past the field (undefined
+# in Taichi's release mode); that entry reads as 0 here.
+def interp_velocity(s):
+    prm = s.prm
+    T = prm.T
+    nx, ny = prm.nx, prm.ny
+    V = np.zeros((nx + 2, ny + 2, 2), dtype=T)
+    upad = np.vstack((s.u, np.zeros((1, ny + 2), dtype=T)))
+    V[1: nx + 2, 1: ny + 1, 0] = (upad[1: nx + 2, 1: ny + 1] + upad[2: nx + 3, 1: ny + 1]) / T(2)
+    V[1: nx + 2, 1: ny + 1, 1] = (s.v[1: nx + 2, 1: ny + 1] + s.v[1: nx + 2, 2: ny + 2]) / T(2)
+    return V
+
+
 # 2dvof.py:505-528 (solver part of the main loop)
 def step(s, nsteps=1, jacobi_iters=10):
     for _ in range(nsteps):

@@ -113,6 +113,8 @@ struct vof2d_ctx {
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
   hipGraphExec_t gphase[4] = {nullptr, nullptr, nullptr, nullptr};  // phase 0, phase 1, phase 2 odd / even
   int next_phase = 0;
+  void* vis = nullptr;      // scratch for the display fields (vof_get_vis_field / vof_interp_velocity)
+  size_t vis_bytes = 0;
   // built-in in-situ profiler (vof_profile_steps): every launch carries a start/stop event pair
   static constexpr int kMaxTimed = 96;
   hipEvent_t tev[2 * kMaxTimed] = {};
@@ -544,6 +546,7 @@ int vof_destroy(vof2d_handle h) {
     if (h->tev[k]) (void)hipEventDestroy(h->tev[k]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->vis) (void)hipFree(h->vis);
   if (h->d_courant) (void)hipFree(h->d_courant);
   if (h->arena) (void)hipFree(h->arena);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -777,6 +780,60 @@ int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t 
                                reinterpret_cast<char*>(src->fld[fF]) + off_s, bytes, hipMemcpyDeviceToDevice,
                                dst->stream));
   return VOF_OK;
+}
+
+// 2dvof.py:458-492 -- display fields.  The image / vector field is produced on the device into a
+// scratch buffer allocated on first use and copied to the caller's dense host array.
+static int vis_scratch(vof2d_handle h, size_t bytes) {
+  if (h->vis_bytes >= bytes) return VOF_OK;
+  if (h->vis) (void)hipFree(h->vis);
+  h->vis = nullptr;
+  h->vis_bytes = 0;
+  if (hipMalloc(&h->vis, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(h, VOF_ENOMEM, "hipMalloc of the visualisation buffer failed");
+  }
+  h->vis_bytes = bytes;
+  return VOF_OK;
+}
+int vof_get_vis_field(vof2d_handle h, const char* which, void* dst, size_t nbytes) {
+  if (!h || !which || !dst) return VOF_EINVAL;
+  if (!(h->g.wall_lo && h->g.wall_hi)) return fail(h, VOF_ESTATE, "display fields need a full-domain handle");
+  int mode = !strcmp(which, "vof") ? 0 : !strcmp(which, "u") ? 1 : !strcmp(which, "v") ? 2 : !strcmp(which, "vnorm") ? 3 : -1;
+  if (mode < 0) return fail(h, VOF_EINVAL, "display field must be vof, u, v or vnorm");
+  const size_t bytes = (size_t)4 * h->g.nx * h->g.ny * h->esz;
+  if (nbytes != bytes) return fail(h, VOF_EINVAL, "buffer must be (2*nx, 2*ny) of the field dtype");
+  int rc = vis_scratch(h, bytes);
+  if (rc) return rc;
+  dim3 grid((2 * h->g.ny + 255) / 256, 2 * h->g.nx);
+  const double umax = h->d.Lx / 0.2, vmax = h->d.Ly / 0.2;  // :468, :476, :484
+  if (h->d.dtype == VOF_F64)
+    launch(h, kOther, k_vis_field<double>, grid, 0, h->g, (const double*)F_<double>(h, fF), (const double*)F_<double>(h, fU),
+           (const double*)F_<double>(h, fV), (double*)h->vis, mode, umax, vmax);
+  else
+    launch(h, kOther, k_vis_field<float>, grid, 0, h->g, (const float*)F_<float>(h, fF), (const float*)F_<float>(h, fU),
+           (const float*)F_<float>(h, fV), (float*)h->vis, mode, (float)umax, (float)vmax);
+  HIPCHK(h, hipMemcpyAsync(dst, h->vis, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ensure_ok(h);
+}
+int vof_interp_velocity(vof2d_handle h, void* dst, size_t nbytes) {
+  if (!h || !dst) return VOF_EINVAL;
+  if (!(h->g.wall_lo && h->g.wall_hi)) return fail(h, VOF_ESTATE, "interp_velocity needs a full-domain handle");
+  const size_t bytes = (size_t)2 * (h->g.nx + 2) * (h->g.ny + 2) * h->esz;
+  if (nbytes != bytes) return fail(h, VOF_EINVAL, "buffer must be (nx+2, ny+2, 2) of the field dtype");
+  int rc = vis_scratch(h, bytes);
+  if (rc) return rc;
+  dim3 grid((h->g.ny + 2 + 255) / 256, h->g.nx + 2);
+  if (h->d.dtype == VOF_F64)
+    launch(h, kOther, k_interp_velocity<double>, grid, 0, h->g, (const double*)F_<double>(h, fU),
+           (const double*)F_<double>(h, fV), (double*)h->vis);
+  else
+    launch(h, kOther, k_interp_velocity<float>, grid, 0, h->g, (const float*)F_<float>(h, fU),
+           (const float*)F_<float>(h, fV), (float*)h->vis);
+  HIPCHK(h, hipMemcpyAsync(dst, h->vis, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ensure_ok(h);
 }
 
 int vof_set_param(vof2d_handle h, const char* name, double value) {

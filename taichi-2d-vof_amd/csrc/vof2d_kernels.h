@@ -280,6 +280,48 @@ __global__ __launch_bounds__(256) void k_post(Geom g, T* __restrict__ F, T* __re
   F2[o] = f;
 }
 
+// ------------------------------------------------------------------ visualisation fields
+// 2dvof.py:458-485 get_vof_field / get_u_field / get_v_field / get_vnorm_field: the (2nx, 2ny)
+// image rgb_buf[I] = field[I // r] (r = 2), i.e. the *stored* entries [0, nx) x [0, ny) -- ghost
+// index 0 included, nx and nx+1 not -- each repeated 2 x 2.  mode 0: F; 1: u / (Lx/0.2);
+// 2: v / (Ly/0.2); 3: sqrt(u^2 + v^2) / (Ly/0.2).  img is dense, row-major (2nx, 2ny).
+template <typename T>
+__global__ __launch_bounds__(256) void k_vis_field(Geom g, const T* __restrict__ F, const T* __restrict__ u,
+                                                    const T* __restrict__ v, T* __restrict__ img, int mode,
+                                                    T umax, T vmax) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;  // image column index (y)
+  const int a = blockIdx.y;                             // image row index (x)
+  if (b >= 2 * g.ny || a >= 2 * g.nx) return;
+  const size_t o = at(g, a / 2, b / 2);
+  T val;
+  if (mode == 0) val = F[o];
+  else if (mode == 1) val = u[o] / umax;
+  else if (mode == 2) val = v[o] / vmax;
+  else val = dsqrt<T>(u[o] * u[o] + v[o] * v[o]) / vmax;
+  img[(size_t)a * (size_t)(2 * g.ny) + b] = val;
+}
+
+// 2dvof.py:488-492 interp_velocity: V[i,j] = ((u[i,j]+u[i+1,j])/2, (v[i,j]+v[i,j+1])/2) for
+// i in [1, nx+1], j in [1, ny].  At i = nx+1 the reference indexes u[nx+2, j], one row past the
+// field (undefined in Taichi's release mode); it reads as 0 here.  out is dense (nx+2, ny+2, 2),
+// entries outside the loop range stay 0 like the zero-initialised ti.Vector.field.
+template <typename T>
+__global__ __launch_bounds__(256) void k_interp_velocity(Geom g, const T* __restrict__ u, const T* __restrict__ v,
+                                                          T* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j > g.ny + 1 || i > g.nx + 1) return;
+  T vx = (T)0, vy = (T)0;
+  if (i >= 1 && j >= 1 && j <= g.ny) {
+    const T unext = i + 1 <= g.nx + 1 ? u[at(g, i + 1, j)] : (T)0;
+    vx = (u[at(g, i, j)] + unext) / (T)2;
+    vy = (v[at(g, i, j)] + v[at(g, i, j + 1)]) / (T)2;
+  }
+  const size_t o = ((size_t)i * (size_t)(g.ny + 2) + j) * 2;
+  out[o] = vx;
+  out[o + 1] = vy;
+}
+
 // ------------------------------------------------------------------ normals
 // 2dvof.py:285-306 get_normal_young loop 1: F (3x3) -> mx, my on interior rows.
 template <typename T, int V>

@@ -74,6 +74,8 @@ SIGNATURES = {
     "field_view": (C.c_int, [H, _str, C.POINTER(C.c_void_p), C.POINTER(_i64), C.POINTER(_i64),
                              C.POINTER(_i64)]),
     "copy_rows": (C.c_int, [H, H, _str, _i32, _i32]),
+    "get_vis_field": (C.c_int, [H, _str, C.c_void_p, C.c_size_t]),
+    "interp_velocity": (C.c_int, [H, C.c_void_p, C.c_size_t]),
     "set_param": (C.c_int, [H, _str, _dbl]),
     "get_param": (C.c_int, [H, _str, C.POINTER(_dbl)]),
     "get_counter": (C.c_int, [H, _str, C.POINTER(_i64)]),

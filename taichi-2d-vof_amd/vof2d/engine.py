@@ -171,6 +171,19 @@ class Engine:
         self._ck(self.api.set_rows(self._h, name.encode(), int(g0), int(g1),
                                    a.ctypes.data_as(C.c_void_p), a.nbytes), "set_rows(%s)" % name)
 
+    def vis_field(self, which):
+        """rgb_buf of get_vof_field / get_u_field / get_v_field / get_vnorm_field (2dvof.py:458-486)."""
+        out = np.empty((2 * self.nx, 2 * self.ny), dtype=self.np_dtype)
+        self._ck(self.api.get_vis_field(self._h, which.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes),
+                 "get_vis_field(%s)" % which)
+        return out
+
+    def interp_velocity(self):
+        """V of interp_velocity (2dvof.py:488-492): (nx+2, ny+2, 2)."""
+        out = np.empty((self.nx + 2, self.ny + 2, 2), dtype=self.np_dtype)
+        self._ck(self.api.interp_velocity(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes), "interp_velocity")
+        return out
+
     def field_view(self, name):
         """(device base pointer, pitch, col0, nrows) -- element (i, j) at
         base + ((i-row_lo)*pitch + col0 + j) * itemsize."""

@@ -100,6 +100,22 @@ class VOF2D:
     def post_process_f(self):
         self.eng.post_process_f()
 
+    # display fields (2dvof.py:458-492) -------------------------------------------
+    def get_vof_field(self):
+        return self.eng.vis_field("vof")
+
+    def get_u_field(self):
+        return self.eng.vis_field("u")
+
+    def get_v_field(self):
+        return self.eng.vis_field("v")
+
+    def get_vnorm_field(self):
+        return self.eng.vis_field("vnorm")
+
+    def interp_velocity(self):
+        return self.eng.interp_velocity()
+
     # main loop --------------------------------------------------------------
     def step(self, nsteps=1):
         self.eng.step(nsteps)

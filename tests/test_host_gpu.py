@@ -42,15 +42,17 @@ def test_reference_shaped_interface(hip_api, oracle_api):
 def test_command_line_is_a_drop_in(tmp_path):
     """python 2dvof.py -ic 2 -s: banner, status line every 100 steps, output/NNNNNN-f.png (2dvof.py:95-99,533,563-571)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "2dvof.py"), "-ic", "2", "-s", "--steps", "200",
-                        "--nx", "64", "--ny", "64"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+                        "--nx", "64", "--ny", "64", "--vis", "3"], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=300)
     assert r.returncode == 0, r.stderr
     out = r.stdout
     assert ">>> Grid resolution: 64 x 64, dt = 4.00e-06" in out
     assert ">>> Density ratio:  20.00, gravity : -5.00, sigma :  0.01" in out
-    assert ">>> Number of steps:100  , Time:4.00e-04 sec. Displaying VOF field." in out
+    assert ">>> Number of steps:100  , Time:4.00e-04 sec. Displaying velocity norm." in out
     assert ">>> Number of steps:200  , Time:8.00e-04 sec." in out
     assert (tmp_path / "output" / "000000-f.png").stat().st_size > 1000
     assert (tmp_path / "output" / "000001-f.png").exists() and (tmp_path / "data").is_dir()
+    assert (tmp_path / "output" / "000000-vis.png").stat().st_size > 200
 
 
 def test_strip_solver_aliases_device_memory():
@@ -73,3 +75,20 @@ def test_strip_solver_aliases_device_memory():
         t[:, col0 + 1: col0 + 65] = 3.5          # write through torch ...
     torch.cuda.synchronize()
     assert np.all(s.eng.get("p", (10, 12))[:, 1:65] == 3.5)   # ... read back through the C ABI
+
+
+def test_display_fields(hip_api, oracle_api):
+    """get_vof_field / get_u_field / get_v_field / get_vnorm_field / interp_velocity (2dvof.py:458-492)."""
+    for dtype in ("f64", "f32"):
+        a, b = engine(hip_api, 40, 56, dtype, "f32", ic=3), engine(oracle_api, 40, 56, dtype, "f32", ic=3)
+        a.step(40); b.step(40)
+        for which in ("vof", "u", "v", "vnorm"):
+            x, y = a.vis_field(which), b.vis_field(which)
+            assert x.shape == (80, 112) and same(x, y), diff_report(x, y, which)
+        assert same(a.interp_velocity(), b.interp_velocity())
+    from vof2d.engine import VofError
+    with pytest.raises(VofError):
+        a.vis_field("pressure")
+    strip = engine(hip_api, 64, 32, "f64", "f32", ic=1, rows=(0, 40), own=(1, 24))
+    with pytest.raises(VofError):
+        strip.vis_field("vof")

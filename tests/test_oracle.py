@@ -147,3 +147,19 @@ def test_phased_step_equals_literal_main_loop(oracle_api):
             for f in ("F", "u", "v", "p", "u_star", "v_star"):
                 assert same(a.get(f), b.get(f)), "ic %d step %d %s" % (ic, step, diff_report(a.get(f), b.get(f), f))
         assert a.istep == b.istep == 15
+
+
+def test_display_fields_numpy_vs_c(oracle_api):
+    """2dvof.py:458-492: get_*_field images and interp_velocity, both restatements."""
+    s = onp.new_state(24, 18, 2, dtype=np.float64)
+    e = engine(oracle_api, 24, 18, "f64", "f32", ic=2)
+    onp.step(s, 30)
+    e.step(30)
+    for which in ("vof", "u", "v", "vnorm"):
+        img = e.vis_field(which)
+        assert img.shape == (48, 36)
+        assert same(img, onp.vis_field(s, which)), which
+    assert same(e.vis_field("vof")[:2, :2], np.full((2, 2), s.F[0, 0]))   # ghost entry 0, repeated 2 x 2
+    V = e.interp_velocity()
+    assert V.shape == (26, 20, 2) and same(V, onp.interp_velocity(s))
+    assert not V[0].any() and not V[:, 0].any() and not V[:, 19].any()
