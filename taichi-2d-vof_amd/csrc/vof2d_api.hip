@@ -84,6 +84,39 @@ Consts<T> round_consts(const ConstsD& s) {
   return c;
 }
 
+// div_by_const (vof2d_kernels.h) returns the correctly rounded a / b from y = RN(1/b) for every
+// denominator except one whose significand is all ones (Markstein).  The denominators it is used
+// with are a handful of constants; refuse the (practically impossible) bad ones at creation.
+template <typename T>
+bool all_ones_significand(T b) {
+  if (sizeof(T) == 8) {
+    uint64_t u;
+    double d = (double)b;
+    memcpy(&u, &d, 8);
+    return (u & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+  }
+  uint32_t u;
+  float f = (float)b;
+  memcpy(&u, &f, 4);
+  return (u & 0x7FFFFFu) == 0x7FFFFFu;
+}
+template <typename T>
+bool divisors_ok(const ConstsD& s) {
+  const Consts<T> c = round_consts<T>(s);
+  if (all_ones_significand(c.dx) || all_ones_significand(c.dy) || all_ones_significand(c.dt) ||
+      all_ones_significand(c.dxdy))
+    return false;
+  for (int e = 0; e <= 2; ++e)      // ap = -(ae + aw + an + as), each term present or 0 (2dvof.py:258-262)
+    for (int n = 0; n <= 2; ++n) {
+      if (e + n == 0) continue;
+      T ap = (T)0;
+      for (int k = 0; k < e; ++k) ap = ap + c.dxi2;
+      for (int k = 0; k < n; ++k) ap = ap + c.dyi2;
+      if (all_ones_significand(ap)) return false;
+    }
+  return true;
+}
+
 }  // namespace
 
 struct vof2d_ctx {
@@ -479,6 +512,10 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   h->err[0] = 0;
   h->d = *d;
   compute_consts(*d, h->cd);
+  if (!(d->dtype == VOF_F64 ? divisors_ok<double>(h->cd) : divisors_ok<float>(h->cd))) {
+    delete h;
+    return VOF_EINVAL;  // a grid/time-step constant with an all-ones significand (see divisors_ok)
+  }
   h->esz = d->dtype == VOF_F64 ? 8 : 4;
   h->V = 16 / (int)h->esz;
   const int W = 64 * h->V;
