@@ -630,14 +630,25 @@ int vof_update_uv(vof2d_handle h) {
   DISPATCH_T(h, L<double>::correct<true>(h), L<float>::correct<true>(h));
   return ensure_ok(h);
 }
+// A single sweep swaps F with its twin, so field pointers baked into captured step graphs go
+// stale: drop the graphs (they are re-captured on the next vof_step / vof_step_phase).
+static void sweep_swapped(vof2d_handle h) {
+  bool any = h->gexec[0] || h->gexec[1];
+  for (int k = 0; k < 4; ++k) any = any || h->gphase[k];
+  if (!any) return;
+  (void)hipStreamSynchronize(h->stream);
+  destroy_graphs(h);
+}
 int vof_fct_x_sweep(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   DISPATCH_T(h, (sweep_x<double, false, false>(h)), (sweep_x<float, false, false>(h)));
+  sweep_swapped(h);
   return ensure_ok(h);
 }
 int vof_fct_y_sweep(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   DISPATCH_T(h, (sweep_y<double, false, false>(h)), (sweep_y<float, false, false>(h)));
+  sweep_swapped(h);
   return ensure_ok(h);
 }
 int vof_solve_VOF_rudman(vof2d_handle h, int64_t istep) {

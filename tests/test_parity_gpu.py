@@ -328,3 +328,18 @@ def test_baseline_8192_eight_strips_on_one_gpu(hip_api):
             g0 = 0 if s.own_lo == 1 else s.own_lo
             g1 = n + 1 if s.own_hi == n else s.own_hi
             assert_fields_same(s, full, STATE, rows=(g0, g1), ctx="step %d strip %d..%d" % (step, s.own_lo, s.own_hi))
+
+
+def test_graph_replay_survives_single_sweep_verbs(hip_api, oracle_api):
+    """A single fct sweep swaps F with its twin buffer; step graphs captured before it must not be
+    replayed with the stale pointers."""
+    a, b = engine(hip_api, 48, 40, "f64", "f32", ic=2), engine(oracle_api, 48, 40, "f64", "f32", ic=2)
+    for e in (a, b):
+        e.step(4)            # graphs for both parities captured here
+        e.fct_x_sweep()      # odd number of swaps
+        e.set_BC()
+        e.step(3)
+        e.fct_y_sweep(); e.fct_x_sweep(); e.fct_y_sweep()
+        e.set_BC()
+        e.step(2)
+    assert_fields_same(a, b, STATE, ctx="steps interleaved with single sweeps")
