@@ -343,3 +343,21 @@ def test_graph_replay_survives_single_sweep_verbs(hip_api, oracle_api):
         e.set_BC()
         e.step(2)
     assert_fields_same(a, b, STATE, ctx="steps interleaved with single sweeps")
+
+
+@pytest.mark.parametrize("iters", [0, 1, 4, 7, 11, 15])
+def test_other_sweep_counts(hip_api, oracle_api, iters):
+    """jacobi_iters other than the reference's 10: launches of 5 / 2 / 1 fused sweeps in every mix,
+    odd launch counts (result copied back from the ping-pong buffer), zero sweeps."""
+    a = engine(hip_api, 72, 50, "f64", "f32", ic=1, jacobi_iters=iters)
+    b = engine(oracle_api, 72, 50, "f64", "f32", ic=1, jacobi_iters=iters)
+    a.step(5); b.step(5)
+    # rhs is built inside solve_p_jacobi in the reference (:239-241): with 0 sweeps it never exists there
+    scratch = SCRATCH if iters else ("u_star", "v_star")
+    assert_fields_same(a, b, STATE + scratch, ctx="jacobi_iters=%d" % iters)
+    # non-square cells take the general (per-term coefficient) fused kernel
+    c = engine(hip_api, 64, 40, "f64", "f32", ic=1, jacobi_iters=iters, Lx=0.1, Ly=0.05)
+    d = engine(oracle_api, 64, 40, "f64", "f32", ic=1, jacobi_iters=iters, Lx=0.1, Ly=0.05)
+    assert c.get_param("dxi2") != c.get_param("dyi2")
+    c.step(4); d.step(4)
+    assert_fields_same(c, d, STATE + scratch, ctx="non-square cells, jacobi_iters=%d" % iters)
