@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 
 #include "../../include/vof2d.h"
@@ -184,9 +185,55 @@ int field_id(const char* name) {
 
 template <typename T> T* F_(vof2d_ctx* h, int id) { return reinterpret_cast<T*>(h->fld[id]); }
 
-// Rows per wave chunk.  Every marching kernel trades lead-in / halo rows per chunk against the
-// number of waves; with few cells the critical path of one wave (rows it marches sequentially,
-// each a dependent load) dominates, so chunks shrink until ~16 waves per CU are in flight.
+// Rows per wave chunk.  Every marching kernel trades lead-in / halo rows per chunk (re-read from
+// HBM by the vertical neighbour) against the number of waves.  Two effects decide:
+//  * residency rounds: a launch whose waves exceed what the chip holds at once (occupancy x 1024
+//    SIMDs) by a little runs a nearly empty extra round (measured on k_jacobi_tb at 4096^2: 3010
+//    waves 116 us, 3080 waves 158 us), so the chunk length is chosen to make the launch k full
+//    rounds, k as small as the maximum chunk length allows;
+//  * with few cells the critical path of one wave dominates, so chunks never exceed what keeps
+//    one round's worth of waves busy (short chunks on small grids).
+// Occupancy comes from the runtime's query for the actual kernel (it depends on the compiled
+// register count); a 5 % margin absorbs the over-reporting noted in MI355X_MICROARCH.md.
+// Used for the two register-heavy, long-lived-wave kernels (k_jacobi_tb: -15 us per step at
+// 4096^2, k_momentum: -3 us); the HBM-bound kernels with short-lived waves measured best with the
+// plain cells-per-wave rule (chunk_rows) and keep it.
+template <typename K>
+long resident_waves(vof2d_ctx* h, K kernel) {
+  static std::map<const void*, long> cache;  // per kernel function
+  const void* key = reinterpret_cast<const void*>(kernel);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int blocks_per_cu = 0;
+  long cap = 3L * 256 * 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) == hipSuccess && blocks_per_cu > 0) {
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    if (blocks_per_cu > 8) blocks_per_cu = 8;  // 32 waves per CU
+    cap = (long)blocks_per_cu * cus * 4;
+  } else {
+    (void)hipGetLastError();
+  }
+  cache[key] = cap;
+  return cap;
+}
+int chunk_rows_fit(const vof2d_ctx* h, int ntiles, long capacity, int rmin, int rmax) {
+  const long rows = h->g.ihi - h->g.ilo + 1;
+  const long cap = capacity * 95 / 100;
+  int R_out = rmin;
+  for (int k = 1; k <= 64; ++k) {
+    long chunks_max = k * cap / ntiles;
+    if (chunks_max < 1) continue;
+    long R = (rows + chunks_max - 1) / chunks_max;
+    if (R <= rmax) { R_out = (int)(R < rmin ? rmin : R); break; }
+  }
+  if (getenv("VOF2D_DEBUG"))
+    fprintf(stderr, "[vof2d] chunk_rows_fit: rows=%ld tiles=%d capacity=%ld -> R=%d (%ld waves)\n", rows, ntiles,
+            capacity, R_out, ((rows + R_out - 1) / R_out) * ntiles);
+  return R_out;
+}
 int chunk_rows(const vof2d_ctx* h, int ntiles, int rmin, int rmax) {
   const long rows = h->g.ihi - h->g.ilo + 1;
   long R = rows * ntiles / 4096;
@@ -272,7 +319,7 @@ struct L {
   static void momentum(vof2d_ctx* h) {
     constexpr int Wt = 64 * V, Ht = ((2 + V - 1) / V) * V, ST = Wt - 2 * Ht;
     const int ntt = (h->g.ny + ST - 1) / ST;
-    const int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows(h, ntt, 4, 32);
+    const int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, resident_waves(h, k_momentum<T, V>), 4, 64);
     launch(h, kMomentum, k_momentum<T, V>, dim3(blocks_for(h, ntt, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
            (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt);
   }
@@ -297,9 +344,8 @@ struct L {
     constexpr int Wt = 64 * V;
     const int Ht = ((TS - 1 + (sq ? 1 : 0) + V - 1) / V) * V, ST = Wt - 2 * Ht;  // must match the kernel
     const int ntt = (h->g.ny + ST - 1) / ST;
-    // short chunks: 2*TS-1 lead-in rows cost ~30 % extra stage work, but the kernel is bound by
-    // exposed load latency at 3 waves/SIMD, which more (shorter) waves hide better (measured)
-    const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows(h, ntt, 4, 16);
+    const long cap = sq ? resident_waves(h, k_jacobi_tb<T, V, TS, true>) : resident_waves(h, k_jacobi_tb<T, V, TS, false>);
+    const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 64);
     if (sq)
       launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
              (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
