@@ -234,12 +234,17 @@ int chunk_rows_fit(const vof2d_ctx* h, int ntiles, long capacity, int rmin, int 
             capacity, R_out, ((rows + R_out - 1) / R_out) * ntiles);
   return R_out;
 }
+// cells-per-wave rule for the streaming kernels: ~4096 waves, chunk length a power of two
+// (measured on k_jacobi at 4096^2: 8/16/32/64 rows 78 us, 24/40/48/96 rows 85-96 us -- the row
+// offsets of concurrently streaming waves then spread evenly over the HBM channels)
 int chunk_rows(const vof2d_ctx* h, int ntiles, int rmin, int rmax) {
   const long rows = h->g.ihi - h->g.ilo + 1;
   long R = rows * ntiles / 4096;
   if (R < rmin) R = rmin;
   if (R > rmax) R = rmax;
-  return (int)R;
+  long P = 1;
+  while (P * 2 <= R) P *= 2;
+  return (int)(P < rmin ? rmin : P);
 }
 int pick_rows(const vof2d_ctx* h, int ntiles) {
   if (h->rows_override > 0) return h->rows_override;
