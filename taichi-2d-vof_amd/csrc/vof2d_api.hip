@@ -156,6 +156,7 @@ struct vof2d_ctx {
   int tkid[kMaxTimed];        // kernel id of each recorded launch
   double prof_sum_ms[16] = {};
   long prof_cnt[16] = {};
+  std::map<const void*, long> occ_cache;  // resident waves per kernel function (resident_waves)
   char err[512];
 };
 
@@ -200,7 +201,7 @@ template <typename T> T* F_(vof2d_ctx* h, int id) { return reinterpret_cast<T*>(
 // plain cells-per-wave rule (chunk_rows) and keep it.
 template <typename K>
 long resident_waves(vof2d_ctx* h, K kernel) {
-  static std::map<const void*, long> cache;  // per kernel function
+  std::map<const void*, long>& cache = h->occ_cache;  // per handle (one host thread per handle)
   const void* key = reinterpret_cast<const void*>(kernel);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
