@@ -87,6 +87,7 @@ class StripSolver:
         self.eng = Engine(api, desc, stream=stream_ptr)
         self.eng.set_init_F(ic)
         self._views = {}
+        self._ops = {}
         self._build_views()
 
     # -- zero-copy tensor views of the exchanged fields -----------------------------
@@ -114,21 +115,34 @@ class StripSolver:
         return t[g0 - self.rows[0]: g1 - self.rows[0] + 1]
 
     # -- exchange ----------------------------------------------------------------------
+    def _p2p_ops(self, f):
+        """The (cached) send/recv descriptors of one field: W owned rows out, W halo rows in, per
+        neighbour.  Row views alias library memory whose address is stable across whole steps; the
+        cache is dropped if a single-sweep verb swapped the F buffers (`_rows_view` re-aliases)."""
+        base = self.eng.field_view(f)[0]
+        hit = self._ops.get(f)
+        if hit is not None and hit[0] == base:
+            return hit[1]
+        dist, W = self.dist, self.halo
+        lo, hi = self.own
+        ops = []
+        if self.rank > 0:  # lower neighbour owns rows < lo
+            ops.append(dist.P2POp(dist.isend, self._rows_view(f, lo, lo + W - 1), self.rank - 1))
+            ops.append(dist.P2POp(dist.irecv, self._rows_view(f, lo - W, lo - 1), self.rank - 1))
+        if self.rank < self.world - 1:
+            ops.append(dist.P2POp(dist.isend, self._rows_view(f, hi - W + 1, hi), self.rank + 1))
+            ops.append(dist.P2POp(dist.irecv, self._rows_view(f, hi + 1, hi + W), self.rank + 1))
+        self._ops[f] = (base, ops)
+        return ops
+
     def _exchange_async(self, fields):
         """Post the halo send/recvs of `fields` with both neighbours as one batched P2P group;
         returns the outstanding works.  RCCL orders the transfers after everything already
         enqueued on the solver's stream and runs them on its own stream."""
-        dist, W = self.dist, self.halo
-        lo, hi = self.own
         ops = []
         for f in fields:
-            if self.rank > 0:  # lower neighbour owns rows < lo
-                ops.append(dist.P2POp(dist.isend, self._rows_view(f, lo, lo + W - 1), self.rank - 1))
-                ops.append(dist.P2POp(dist.irecv, self._rows_view(f, lo - W, lo - 1), self.rank - 1))
-            if self.rank < self.world - 1:
-                ops.append(dist.P2POp(dist.isend, self._rows_view(f, hi - W + 1, hi), self.rank + 1))
-                ops.append(dist.P2POp(dist.irecv, self._rows_view(f, hi + 1, hi + W), self.rank + 1))
-        return dist.batch_isend_irecv(ops) if ops else []
+            ops += self._p2p_ops(f)
+        return self.dist.batch_isend_irecv(ops) if ops else []
 
     def exchange(self, fields=EXCHANGED):
         """Refresh the halo rows of `fields` from both neighbours and wait for them."""
