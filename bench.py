@@ -244,6 +244,26 @@ def main():
         fused.update({"us_per_launch_in_step": us_in_step, "us_per_sweep_in_step": us_in_step / tb,
                       "ms_per_step_without_sweeps": ms0,
                       "algorithmic_GBs_in_step": sweep_bytes * tb / (us_in_step * 1e-6) / 1e9})
+    # The N > 1 runs strong-scale 8192^2; give the single-GPU figure for that grid too, so the
+    # scaling series has its own N = 1 point (only when the workload was not overridden).
+    ref8192 = None
+    if not dist_path and not a.nx and rank == 0:
+        try:
+            from vof2d.engine import Engine as _E2, make_desc as _md2
+            e8 = _E2(api, _md2(api, 8192, 8192, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters))
+            e8.set_init_F(a.ic)
+            e8.step(3)
+            e8.sync()
+            t0 = time.perf_counter()
+            e8.step(12)
+            e8.sync()
+            dt8 = time.perf_counter() - t0
+            e8.close()
+            ref8192 = {"workload": "8192x8192 -ic %d %s, single strip (the grid bench.py --gpus N > 1 strong-scales)" % (
+                a.ic, a.dtype), "value": 8192 * 8192 * 12 / dt8, "unit": "cell-updates/s", "ms_per_step": 1e3 * dt8 / 12,
+                "steps": 12}
+        except Exception as exc:   # e.g. not enough free HBM
+            ref8192 = {"error": str(exc)}
     prof = eng.profile_steps(14) if not dist_path else {}
     kernels_us = {k: round(v[0], 2) for k, v in prof.items()}
 
@@ -274,6 +294,7 @@ def main():
                          "us_per_launch": 1e3 * ms_sweep_1, "algorithmic_bytes_per_launch": sweep_bytes,
                          "launches_timed": max(2, a.jacobi_sweeps_timed // 2 * 2)},
             "jacobi_fused": fused,
+            "strong_scaling_reference_n1": ref8192,
             "step_hbm_gbs_algorithmic": (ARRAYS_PER_STEP if not dist_path else ARRAYS_PER_STEP + 2) * esz * nx * ny * a.steps / elapsed / 1e9,
             "kernels_us_dispatch_start_to_stop": kernels_us,
             "courant_violations": violations,
