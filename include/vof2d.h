@@ -171,6 +171,14 @@ int vof_reset_profile(vof2d_handle h);
  * handle's stream; *ms_per_sweep = elapsed / n.  p advances by n sweeps.  Uses the kernels the
  * step uses (k_jacobi_tb launches of `jacobi_tb` sweeps, k_jacobi when that parameter is 1). */
 int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep);
+/* Self-test of the kernels' exact constant-denominator division (the Jacobi update p = num / ap,
+ * 2dvof.py:262-264, and the / dx, / dy, / dt, / (dx*dy) of :207-232 and :327-449 are evaluated as
+ * Markstein-corrected multiplications by the reciprocal): n generated (numerator, denominator)
+ * pairs -- ordinary, tiny, huge, special, and subnormal quotients on and beside the midpoints of
+ * the subnormal grid -- are divided by that routine on the current device.  a_out, b_out, q_out:
+ * host arrays of n elements of `dtype`; the caller checks q == a / b with the host's IEEE division
+ * (tests/test_parity_gpu.py). */
+int vof_selftest_division(int32_t dtype, int64_t n, uint64_t seed, void* a_out, void* b_out, void* q_out);
 const char* vof_last_error(vof2d_handle h);
 /* "hip-gfx950" for the product library, "cpu-oracle" for oracle/ */
 const char* vof_backend(void);

@@ -217,24 +217,28 @@ int ovof_step(vof2d_handle h, int64_t nsteps) {
   return VOF_OK;
 }
 /* The step cut at the points where p / u,v / F become final, with each field's boundary condition
- * applied once right after (the schedule of the HIP library's vof_step_phase, include/vof2d.h).
+ * applied once (the schedule of the HIP library's vof_step_phase, include/vof2d.h): phase 0 ends
+ * with p (and F) ghosts set, phase 1 = update_uv + u,v ghosts + the first FCT sweep, phase 2 = the
+ * second sweep + post_process_f + F ghosts.
  * Test double for the overlapped halo exchange; ovof_step above stays the literal main loop. */
 int ovof_step_phase(vof2d_handle h, int32_t phase) {
   if (!h || phase < 0 || phase > 2) return VOF_EINVAL;
   if (phase != h->next_phase) return VOF_ESTATE;
   h->next_phase = (phase + 1) % 3;
+  const int y_first = (h->istep + (phase == 0)) % 2 == 0; /* 2dvof.py:312-318 */
   if (phase == 0) {
     h->istep += 1;
     ovof_cal_nu_rho(h);
     ovof_get_normal_young(h);
     ovof_advect_upwind(h);
     ovof_solve_p_jacobi(h, h->d.jacobi_iters);
-    DISPATCH(h, set_BC_mask, 4);
+    DISPATCH(h, set_BC_mask, 4 | 2);
   } else if (phase == 1) {
     ovof_update_uv(h);
-    DISPATCH(h, set_BC_mask, 1 | 2 | 8);
+    DISPATCH(h, set_BC_mask, 1 | 8);
+    if (y_first) ovof_fct_y_sweep(h); else ovof_fct_x_sweep(h);
   } else {
-    ovof_solve_VOF_rudman(h, h->istep);
+    if (y_first) ovof_fct_x_sweep(h); else ovof_fct_y_sweep(h);
     /* post_process_f on the interior (on ghosts it is dead: the F boundary condition follows) */
     ovof_post_process_f(h);
     DISPATCH(h, set_BC_mask, 2);

@@ -145,7 +145,7 @@ struct vof2d_ctx {
   int fuse_momentum = 1;
   int fuse_correct = 1; // vof_step on a full domain: update_uv inside the first FCT sweep
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
-  hipGraphExec_t gphase[4] = {nullptr, nullptr, nullptr, nullptr};  // phase 0, phase 1, phase 2 odd / even
+  hipGraphExec_t gphase[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // phase 0, phase 1 even / odd, phase 2 even / odd
   int next_phase = 0;
   void* vis = nullptr;      // scratch for the display fields (vof_get_vis_field / vof_interp_velocity)
   size_t vis_bytes = 0;
@@ -436,19 +436,29 @@ void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
 
 // The fused per-step schedule, 2dvof.py:506-528 (DESIGN.md "schedule"), in three phases so a
 // multi-GPU driver can ship each field's halo as soon as the field is final for the step:
-//   phase 0: predictor + pressure solve     -> p final
-//   phase 1: velocity correction + set_BC   -> u, v final
-//   phase 2: VOF transport + set_BC         -> F final
+//   phase 0: predictor + pressure solve                      -> p final
+//   phase 1: velocity correction + first FCT sweep + BC(u,v) -> u, v final
+//   phase 2: second FCT sweep (+post_process_f) + BC(F)      -> F final
+// update_uv (:524) is folded into whichever FCT sweep runs first (that sweep streams F anyway and
+// needs the corrected velocity): p, F, u*, v* -> u, v does not cost its own 6-pass kernel.
 // The reference applies the full set_BC three times per step (:518, :525, :528).  Here each field
-// gets its boundary condition once, as soon as it is final for the step -- p after the sweeps,
-// u / v (and F, whose ghosts the sweeps read) after the correction, F after the transport:
+// gets its boundary condition once, as soon as it is final for the step -- p (and F, whose ghosts
+// the sweeps read; only the first step changes them) after the Jacobi sweeps, u / v after the
+// correction, F after the transport:
 //   * :518 only rewrites ghosts that :525 rewrites again before anything reads them (p ghosts are
 //     read by the Jacobi stencil, but always multiplied by a zero coefficient);
-//   * u, v, p do not change after :525, so :528 rewrites identical values for them.
-// After every phase the ghost cells hold exactly what the reference's calls leave there, and an
-// in-flight halo receive of a field never overlaps a kernel that writes the same field.
+//   * u, v, p do not change after :525, so :528 rewrites identical values for them;
+//   * the first sweep derives the boundary values of u, v it needs itself (corrected_velocity), and
+//     writes them where the second sweep reads them.
+// After every phase the ghost cells of the fields final so far hold exactly what the reference's
+// calls leave there, and an in-flight halo receive of a field never overlaps a kernel that writes
+// the same field.  vof_step on one handle is the three phases back to back; with merge_bc the
+// u, v boundary condition moves behind the second sweep and shares F's launch (full domains only:
+// a strip driver wants u, v complete before it ships them).
 template <typename T>
-void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep) {
+void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false) {
+  const bool y_first = (istep % 2 == 0);    // :526, :312-318
+  const bool corr = h->fuse_correct != 0;
   if (phase == 0) {
     // cal_nu_rho (:513) is folded into its consumers: rho/nu = f(F[i,j]) recomputed per cell
     if (h->fuse_momentum) {
@@ -461,45 +471,25 @@ void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep) {
       L<T>::template rhs<false>(h);         // :521-522, rhs part (iteration invariant)
     }
     jacobi_n<T>(h, h->d.jacobi_iters, false);  // :521-522
-    L<T>::template set_bc<BC_P>(h);         // p part of :525 / :528
+    L<T>::template set_bc<BC_P | BC_F>(h);  // p part of :525 / :528; F part of :518 (first step)
   } else if (phase == 1) {
-    L<T>::template correct<false>(h);       // :524
-    L<T>::template set_bc<BC_UV | BC_F>(h); // u, v, F parts of :525 (F: also what :518 did at step 1)
-  } else {
-    if (istep % 2 == 0) {                   // :526, :312-318; post_process_f (:527) fused into the 2nd sweep
-      sweep_y<T, false>(h);
-      sweep_x<T, true>(h);
+    if (corr) {                             // :524 inside the first sweep of :526
+      if (y_first) sweep_y<T, false, true>(h); else sweep_x<T, false, true>(h);
     } else {
-      sweep_x<T, false>(h);
-      sweep_y<T, true>(h);
+      L<T>::template correct<false>(h);     // :524
     }
-    L<T>::template set_bc<BC_F>(h);         // F part of :528
+    if (!(merge_bc && corr)) L<T>::template set_bc<BC_UV>(h);  // u, v part of :525
+    if (!corr) { if (y_first) sweep_y<T, false>(h); else sweep_x<T, false>(h); }
+  } else {
+    if (y_first) sweep_x<T, true>(h); else sweep_y<T, true>(h);  // second sweep, :527 fused
+    if (merge_bc && corr) L<T>::template set_bc<BC_UV | BC_F>(h);
+    else L<T>::template set_bc<BC_F>(h);    // F part of :528
   }
 }
-// vof_step: the three phases back to back -- except on a full-domain handle, where update_uv
-// (:524) is folded into whichever FCT sweep runs first (that sweep streams F anyway and needs the
-// corrected velocity): p, F, u*, v* -> u, v no longer costs its own 6-pass kernel.  u and v are
-// final before anything reads them (the second sweep, the u/v boundary condition), and p's and
-// F's boundary conditions share one launch.  The phased form keeps the separate kernel because a
-// strip driver ships u, v while the transport runs.
 template <typename T>
 void enqueue_step(vof2d_ctx* h, int64_t istep) {
   const bool full = h->g.wall_lo && h->g.wall_hi;
-  if (!(full && h->fuse_correct && h->fuse_momentum)) {
-    for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep);
-    return;
-  }
-  L<T>::momentum(h);                           // :513-517 + rhs of :239-241
-  jacobi_n<T>(h, h->d.jacobi_iters, false);    // :521-522
-  L<T>::template set_bc<BC_P | BC_F>(h);       // p part of :525/:528; F part of :518 (first step)
-  if (istep % 2 == 0) {                        // :524 + :526 (:312-318) + :527
-    sweep_y<T, false, true>(h);
-    sweep_x<T, true>(h);
-  } else {
-    sweep_x<T, false, true>(h);
-    sweep_y<T, true>(h);
-  }
-  L<T>::template set_bc<BC_UV | BC_F>(h);      // u, v part of :525; F part of :528
+  for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep, full);
 }
 
 int ensure_ok(vof2d_ctx* h) {
@@ -532,7 +522,7 @@ int copy_rows_host(vof2d_ctx* h, int id, int g0, int g1, void* host, size_t nbyt
 void destroy_graphs(vof2d_ctx* h) {
   for (int k = 0; k < 2; ++k)
     if (h->gexec[k]) { (void)hipGraphExecDestroy(h->gexec[k]); h->gexec[k] = nullptr; }
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 5; ++k)
     if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }
 }
 
@@ -686,7 +676,7 @@ int vof_update_uv(vof2d_handle h) {
 // stale: drop the graphs (they are re-captured on the next vof_step / vof_step_phase).
 static void sweep_swapped(vof2d_handle h) {
   bool any = h->gexec[0] || h->gexec[1];
-  for (int k = 0; k < 4; ++k) any = any || h->gphase[k];
+  for (int k = 0; k < 5; ++k) any = any || h->gphase[k];
   if (!any) return;
   (void)hipStreamSynchronize(h->stream);
   destroy_graphs(h);
@@ -761,7 +751,7 @@ int vof_step_phase(vof2d_handle h, int32_t phase) {
     DISPATCH_T(h, enqueue_phase<double>(h, phase, h->istep), enqueue_phase<float>(h, phase, h->istep));
     return ensure_ok(h);
   }
-  const int slot = phase < 2 ? phase : 2 + (int)(h->istep & 1);
+  const int slot = phase == 0 ? 0 : 2 * phase - 1 + (int)(h->istep & 1);
   if (!h->gphase[slot]) {
     hipGraph_t graph = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -1072,6 +1062,74 @@ int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep) {
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *ms_per_sweep = ms / (float)n;
   return ensure_ok(h);
+}
+// ---- self-test of the exact constant-denominator division (vof2d_kernels.h div_by_const) against
+// the hardware IEEE division, on adversarial numerators: subnormal quotients at and next to the
+// midpoints of the subnormal grid (the double-rounding case), tiny / huge / special values.
+}  // extern "C"
+namespace {
+__device__ inline uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
+}
+template <typename T> struct SelfT;
+template <> struct SelfT<double> { static constexpr int emin = -1074, kbits = 51, ebig = 1000; };
+template <> struct SelfT<float> { static constexpr int emin = -149, kbits = 22, ebig = 120; };
+template <typename T>
+__global__ void k_selftest_division(uint64_t seed, int64_t n, T* __restrict__ oa, T* __restrict__ ob, T* __restrict__ oq) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n) return;
+  using S = SelfT<T>;
+  uint64_t h1 = mix64(seed + 4 * (uint64_t)id), h2 = mix64(h1), h3 = mix64(h2), h4 = mix64(h3);
+  auto unit = [](uint64_t h) { return (T)(1.0 + (double)(h >> 11) * 0x1p-53); };  // [1, 2), full significand
+  const int cat = (int)(id % 8);
+  // denominators: |b| in [1, 2^37) like ap of the Jacobi stencil, or in (2^-40, 1) like dx, dt, dx*dy
+  const bool small_b = (cat == 3) || (cat == 7) || (cat == 0 && (h4 & 1));
+  T b = unit(h1) * (T)__builtin_ldexp(1.0, small_b ? -1 - (int)(h2 % 40) : (int)(h2 % 37));
+  if (h2 & (1ull << 50)) b = -b;
+  T a;
+  if (cat == 0 || cat == 7) {                       // ordinary magnitudes over the whole range
+    a = unit(h3) * (T)__builtin_ldexp(1.0, (int)(h4 % (2 * S::ebig)) - S::ebig);
+  } else if (cat == 1) {                            // tiny numerators down to the smallest subnormal
+    a = unit(h3) * (T)__builtin_ldexp(1.0, S::emin + (int)(h4 % 200));
+  } else if (cat == 2 || cat == 5 || cat == 6) {    // subnormal quotient next to / on a grid midpoint
+    if (cat == 5) b = (T)(double)(1 + (h1 % 4095)) * (T)__builtin_ldexp(1.0, (int)(h2 % 20));  // exact ties
+    const int kb = 1 + (int)(h4 % S::kbits);
+    const double k = (double)(h3 >> (64 - kb)) + 0.5;       // midpoint index + 1/2
+    double nn = __builtin_rint(k * (double)dabs<T>(b));      // numerator in units of the smallest subnormal
+    if (cat == 6) nn += (double)((int)(h4 >> 60) - 8);       // a few units beside it
+    a = (T)__builtin_ldexp(nn, S::emin);
+  } else if (cat == 3) {                            // huge numerators over small denominators
+    a = unit(h3) * (T)__builtin_ldexp(1.0, S::ebig - (int)(h4 % 100) + (sizeof(T) == 8 ? 23 : 7));
+  } else {                                          // zeros, infinities, NaN
+    const T sp[6] = {(T)0.0, (T)-0.0, DivLimits<T>::inf, -DivLimits<T>::inf, (T)__builtin_nan(""), DivLimits<T>::denorm_min};
+    a = sp[h3 % 6];
+  }
+  if (h3 & (1ull << 40)) a = -a;
+  const T y = (T)1.0 / b;
+  oa[id] = a;
+  ob[id] = b;
+  oq[id] = dabs<T>(b) < (T)1 ? div_by_const<T, true>(a, b, y) : div_by_const<T, false>(a, b, y);
+}
+}  // namespace
+extern "C" {
+int vof_selftest_division(int32_t dtype, int64_t n, uint64_t seed, void* a_out, void* b_out, void* q_out) {
+  if (!a_out || !b_out || !q_out || n < 1 || (dtype != VOF_F64 && dtype != VOF_F32)) return VOF_EINVAL;
+  const size_t bytes = (size_t)n * (dtype == VOF_F64 ? 8 : 4);
+  char* dev = nullptr;
+  if (hipMalloc(&dev, 3 * bytes) != hipSuccess) { (void)hipGetLastError(); return VOF_ENOMEM; }
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (dtype == VOF_F64)
+    hipLaunchKernelGGL(k_selftest_division<double>, dim3(blocks), dim3(256), 0, 0, seed, n, (double*)dev,
+                       (double*)(dev + bytes), (double*)(dev + 2 * bytes));
+  else
+    hipLaunchKernelGGL(k_selftest_division<float>, dim3(blocks), dim3(256), 0, 0, seed, n, (float*)dev,
+                       (float*)(dev + bytes), (float*)(dev + 2 * bytes));
+  hipError_t e = hipMemcpy(a_out, dev, bytes, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(b_out, dev + bytes, bytes, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(q_out, dev + 2 * bytes, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  return e == hipSuccess ? VOF_OK : VOF_EHIP;
 }
 const char* vof_last_error(vof2d_handle h) { return h ? h->err : "null handle"; }
 const char* vof_backend(void) { return "hip-gfx950"; }

@@ -87,32 +87,63 @@ __device__ __forceinline__ float lane_dn(float x) { return __int_as_float(dpp_dn
 // y = RN(1/b):  q = RN(a*y);  r = a - b*q (exact, one FMA);  RN(q + r*y) is the correctly rounded
 // quotient (Markstein 1990; the same final step the hardware division expansion performs after
 // its Newton iterations), i.e. bit-identical to IEEE a / b, for 3 FMA-rate ops instead of ~11.
-// Outside a safe exponent window (where r could underflow or q overflow) and for a == 0 the code
-// falls back to the true division / the signed zero of a*y, so every input is handled exactly.
+// Outside a safe exponent window the remainder r would underflow (tiny a) or q overflow (huge a
+// with |b| < 1).  There the numerator is scaled by an exact power of two, divided the same way and
+// the quotient Q scaled back:
+//   * tiny a (the decaying front of the Jacobi iteration walks through 1e-280 ... 4.9e-324 on its
+//     way to exact zero): Q * 2^-k is exact while the quotient is normal.  A subnormal quotient is
+//     rounded a second time by that multiplication; the two roundings differ from the single
+//     IEEE one only if Q sits exactly on a midpoint of the subnormal grid (midpoints are
+//     representable, and RN is monotonic) while the true quotient lies beside it -- the sign of
+//     the exact remainder A - b*Q tells on which side, and the tie break is undone if it went the
+//     other way;
+//   * huge a: Q * 2^k is exact or overflows to the same infinity a / b rounds to.
+// a == 0 gives the signed zero of a*y, an infinite a the infinity a*y, a NaN numerator NaN: every
+// input gets the IEEE quotient without the ~11-op hardware expansion (and without a call, which
+// would cost the register-heavy kernels their allocation).
 template <typename T> struct DivLimits;
-template <> struct DivLimits<double> { static constexpr double lo = 1e-280, hi = 1e280; };
-template <> struct DivLimits<float> { static constexpr float lo = 1e-25f, hi = 1e25f; };
+template <> struct DivLimits<double> {
+  static constexpr double lo = 1e-280, hi = 1e280, up = 0x1p+256, dn = 0x1p-256, qmin = 0x1p-766 /* 2^-1022 * up */,
+                          denorm_min = 0x1p-1074, half_step = 0x1p-819 /* denorm_min * up / 2 */,
+                          inf = __builtin_huge_val();
+};
+template <> struct DivLimits<float> {
+  static constexpr float lo = 1e-25f, hi = 1e25f, up = 0x1p+96f, dn = 0x1p-96f, qmin = 0x1p-30f /* 2^-126 * up */,
+                         denorm_min = 0x1p-149f, half_step = 0x1p-54f, inf = __builtin_huge_valf();
+};
 template <typename T> __device__ __forceinline__ T dfma(T a, T b, T c);
 template <> __device__ __forceinline__ double dfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <> __device__ __forceinline__ float dfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// out-of-line so the (practically never taken) hardware division expansion is not replicated
-// into every unrolled call site
 template <typename T>
-__device__ __attribute__((noinline)) T div_slow(T a, T b) { return a / b; }
+__device__ __forceinline__ T div_scaled(T a, T b, T y, T scale) {  // RN((a * scale) / b), scale = 2^+-k
+  const T A = a * scale;
+  const T Q0 = A * y;
+  return dfma<T>(dfma<T>(-b, Q0, A), y, Q0);
+}
 
 template <typename T, bool SMALL_B = false>
 __device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
+  using L = DivLimits<T>;
   const T q = a * y;
   const T r = dfma<T>(-b, q, a);
   T res = dfma<T>(r, y, q);
-  // Tiny numerators, zero and NaN leave the fast path; with |b| < 1 (SMALL_B) also huge ones, where
-  // q could overflow.  (An infinite numerator -- a simulation that has already blown up -- yields
-  // NaN here instead of inf when |b| >= 1.)
   const T aa = dabs<T>(a);
-  if (!(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi))) {
-    res = q;                    // a == 0: signed zero of the quotient
-    if (a != (T)0) res = div_slow<T>(a, b);  // tiny / huge / non-finite numerators: hardware-exact path
+  if (aa < L::lo) {
+    res = q;                                    // a == 0: signed zero of the quotient
+    if (a != (T)0) {
+      const T Q = div_scaled<T>(a, b, y, L::up);
+      res = Q * L::dn;                          // exact if |Q| >= qmin, else RN onto the subnormal grid
+      if (!(dabs<T>(Q) >= L::qmin)) {
+        const T diff = Q - res * L::up;         // exact; +-half_step iff Q is a grid midpoint
+        const T R = dfma<T>(-b, Q, a * L::up);  // exact remainder: true quotient - Q = R / b
+        if (dabs<T>(diff) == L::half_step && R != (T)0 && ((R > (T)0) == (b > (T)0)) == (diff > (T)0))
+          res += diff > (T)0 ? L::denorm_min : -L::denorm_min;
+      }
+    }
+  } else if (SMALL_B && aa > L::hi) {
+    res = q;                                    // infinite a: the infinity a * y
+    if (aa < L::inf) res = div_scaled<T>(a, b, y, L::dn) * L::up;
   }
   return res;
 }
@@ -1197,15 +1228,25 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
         ur[q] = urow ? un : (T)0;
         const T rl = q == 0 ? rhol : rhor[q - 1];
         const T pl = q == 0 ? pr.l : pr.c[q - 1];
-        ov[q] = corrected_velocity<T>(c, vsr[q], rhor[q], rl, pr.c[q], pl, c.dyi);
+        const T vn = corrected_velocity<T>(c, vsr[q], rhor[q], rl, pr.c[q], pl, c.dyi);
+        ov[q] = (j >= 2 && j <= g.ny) ? vn : (T)0;   // v exists on j in [2, ny]
         if (own && j <= g.ny && r >= g.own_lo && r <= g.own_hi) {
           if (urow && ur[q] * c.dt > c.cfl_x) viol++;
           if (j >= 2 && ov[q] * c.dt > c.cfl_y) viol++;
         }
       }
       if (own) {
-        if (urow) store_c<T, V>(Uo + at(g, r, j0), ur, j0, 1, g.ny);
-        store_c<T, V>(Vo + at(g, r, j0), ov, j0, 2, g.ny);
+        // the wall faces u[1], u[nx+1], v[:,1], v[:,ny+1] get set_BC's zeros (:525) here, because
+        // the other sweep reads them before the u, v boundary kernel runs on a full domain
+        store_c<T, V>(Uo + at(g, r, j0), ur, j0, 1, g.ny);
+        store_c<T, V>(Vo + at(g, r, j0), ov, j0, 1, g.ny);
+        if (j0 + V > g.ny) Vo[at(g, r, g.ny + 1)] = (T)0;
+        if (r == g.nx) {
+          T zero[V];
+#pragma unroll
+          for (int q = 0; q < V; ++q) zero[q] = (T)0;
+          store_c<T, V>(Uo + at(g, r + 1, j0), zero, j0, 1, g.ny);
+        }
       }
 #pragma unroll
       for (int q = 0; q < V; ++q) {
@@ -1336,7 +1377,8 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
 #pragma unroll
       for (int q = 0; q < V; ++q) {
         const int j = j0 + q;
-        ou[q] = corrected_velocity<T>(c, usz[q], rhoz[q], rho1[q], pz[q], p1[q], c.dxi);
+        const T un = corrected_velocity<T>(c, usz[q], rhoz[q], rho1[q], pz[q], p1[q], c.dxi);
+        ou[q] = i >= 2 ? un : (T)0;                // u exists on i in [2, nx]
         const T vn = corrected_velocity<T>(c, vz[q], rhoz[q], q == 0 ? rhol : rhoz[q - 1], pz[q],
                                            q == 0 ? pl : pz[q - 1], c.dyi);
         vz[q] = (j >= 2 && j <= ny) ? vn : (T)0;   // v exists on j in [2, ny]; j = 1, ny+1 keep set_BC's 0
@@ -1347,8 +1389,16 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
         p1[q] = pz[q];
         rho1[q] = rhoz[q];
       }
-      if (i >= 2) store_c<T, V>(Uo + o, ou, j0, jlo, jhi);
-      store_c<T, V>(Vo + o, vz, j0, jlo > 2 ? jlo : 2, jhi);
+      // wall faces included (set_BC's zeros, :525): the x sweep reads u[1], u[nx+1] before the
+      // u, v boundary kernel runs on a full domain
+      store_c<T, V>(Uo + o, ou, j0, jlo, jhi);
+      store_c<T, V>(Vo + o, vz, j0, jlo, jhi == ny ? ny + 1 : jhi);
+      if (i == g.nx) {
+        T zero[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) zero[q] = (T)0;
+        store_c<T, V>(Uo + o + g.pitch, zero, j0, jlo, jhi);
+      }
     }
     {  // F identically 0 over the wave's whole row segment: every output of the segment is 0
       bool rz = true;

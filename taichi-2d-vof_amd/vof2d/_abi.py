@@ -86,13 +86,15 @@ SIGNATURES = {
     "profile_steps": (C.c_int, [H, _i64]),
     "get_profile": (C.c_int, [H, _str, C.POINTER(_dbl), C.POINTER(_i64)]),
     "reset_profile": (C.c_int, [H]),
+    "selftest_division": (C.c_int, [_i32, _i64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "last_error": (C.c_char_p, [H]),
     "backend": (C.c_char_p, []),
 }
 
 
 # entry points that only the GPU library implements (timing / profiling on a HIP stream)
-GPU_ONLY = ("timer_start", "timer_stop", "time_jacobi", "profile_steps", "get_profile", "reset_profile")
+GPU_ONLY = ("timer_start", "timer_stop", "time_jacobi", "profile_steps", "get_profile", "reset_profile",
+            "selftest_division")
 
 
 class Api:

@@ -239,3 +239,14 @@ class Engine:
         ms = C.c_float()
         self._ck(self.api.time_jacobi(self._h, int(n), C.byref(ms)), "time_jacobi")
         return ms.value
+
+
+def selftest_division(api, dtype, n, seed):
+    """vof_selftest_division: (a, b, q) arrays with q = the kernels' exact division of a by b."""
+    dt = np.float64 if dtype_code(dtype) == _abi.VOF_F64 else np.float32
+    a, b, q = (np.empty(n, dt) for _ in range(3))
+    rc = api.selftest_division(dtype_code(dtype), n, seed, a.ctypes.data, b.ctypes.data, q.ctypes.data)
+    if rc != 0:
+        raise VofError("vof_selftest_division failed: %s" % _abi.ERRNAMES.get(rc, rc))
+    return a, b, q
+
