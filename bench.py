@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "taichi-2d-vof_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
 # distinct arrays read or written per cell per step by the fused schedule (DESIGN.md "schedule"):
 # k_momentum 6 (F,u,v -> u*,v*,rhs) + 2 x k_jacobi_tb 3 + first FCT sweep with update_uv 7
-# (F,u*,v*,p -> F',u,v) + second FCT sweep 3;  strips (phased schedule): k_correct 6 + 2 x 3 = 24
+# (F,u*,v*,p -> F',u,v) + second FCT sweep 3; strips run the same schedule
 ARRAYS_PER_STEP = 22
 
 
@@ -45,6 +45,16 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed/StripSolver code path even with one rank (self-test)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--dt", type=float, default=0.0,
+                    help="time step (default: the reference's 4e-6, 2dvof.py:33, up to 4096^2; 1e-6 at 8192^2, where "
+                         "4e-6 exceeds the explicit viscous limit dx^2/(4 nu_g) = 2.5e-6 and the reference algorithm "
+                         "-- oracle and GPU alike -- overflows within 10 steps)")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="N > 1: halo exchange by the library's own RCCL communicator (no torch in the process) "
+                         "or by torch.distributed P2P")
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2],
+                    help="N > 1: 0 = one exchange after the step, 1 = each field as soon as it is final, "
+                         "2 = 1 + F's edge bands first (vof_step_exchange)")
     return ap.parse_args()
 
 
@@ -159,14 +169,21 @@ def main():
     nx = a.nx or (4096 if world == 1 else 8192)
     ny = a.ny or nx
     esz = 8 if a.dtype == "f64" else 4
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    def stable_dt(n):
+        return a.dt if a.dt > 0 else (4e-6 if n <= 4096 else 1e-6)
+    dt = stable_dt(max(nx, ny))
 
     dist_path = world > 1 or a.force_dist
+    comm = None
+    exchange = "none"
     if not dist_path:
         # single GPU: no torch in the process at all -- ctypes -> C ABI -> HIP
         from vof2d._lib import hip_api
         from vof2d.engine import Engine, make_desc
         api = hip_api()
-        eng = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters))
+        eng = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters, dt=dt))
         eng.set_init_F(a.ic)
         eng.step(a.warmup)
         eng.sync()
@@ -175,11 +192,30 @@ def main():
         eng.sync()
         elapsed = time.perf_counter() - t0
         solver = None
+    elif a.exchange == "native":
+        # one process per GPU, still no torch: rank / world from the launcher's environment, the
+        # library's own RCCL communicator for halos, barrier and the max over ranks
+        from vof2d.comms import EnvComm
+        from vof2d.strips import StripSolver
+        comm = EnvComm(rank, world, local)
+        with _StdoutToStderr():
+            solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local,
+                                 jacobi_iters=a.jacobi_iters, comm=comm, exchange="native" if world > 1 else "auto", dt=dt)
+            eng = solver.eng
+            solver.step(a.warmup, overlap=a.overlap)
+            eng.sync()
+            solver.barrier()
+        t0 = time.perf_counter()
+        solver.step(a.steps, overlap=a.overlap)
+        eng.sync()          # the compute stream has joined the communication stream of every step
+        solver.barrier()
+        elapsed = time.perf_counter() - t0
+        elapsed = comm.allreduce_max(elapsed, eng)
+        exchange = solver.exchange_kind if world > 1 else "none"
     else:
         import torch
         import torch.distributed as dist
         from vof2d.strips import StripSolver
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:  # --force-dist without a launcher
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
@@ -189,14 +225,14 @@ def main():
         with _StdoutToStderr():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local,
-                                 jacobi_iters=a.jacobi_iters)
+                                 jacobi_iters=a.jacobi_iters, exchange="torch", dt=dt)
             eng = solver.eng
-            solver.step(a.warmup)
+            solver.step(a.warmup, overlap=bool(a.overlap))
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        solver.step(a.steps)
+        solver.step(a.steps, overlap=bool(a.overlap))
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -204,6 +240,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        exchange = "torch" if world > 1 else "none"
 
     # Jacobi kernels.
     # (1) the north-star kernel: k_jacobi, one sweep per launch, 3 array passes, HBM-bound.  Timed
@@ -230,7 +267,7 @@ def main():
     if not dist_path and a.jacobi_iters > 0 and a.jacobi_iters % tb == 0:
         # in-step cost: (step with sweeps - step without sweeps) / launches, both graph-replayed
         from vof2d.engine import Engine as _E, make_desc as _md
-        e0 = _E(api, _md(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=0))
+        e0 = _E(api, _md(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=0, dt=dt))
         e0.set_init_F(a.ic)
         e0.step(a.warmup)
         e0.sync()
@@ -250,7 +287,7 @@ def main():
     if not dist_path and not a.nx and rank == 0:
         try:
             from vof2d.engine import Engine as _E2, make_desc as _md2
-            e8 = _E2(api, _md2(api, 8192, 8192, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters))
+            e8 = _E2(api, _md2(api, 8192, 8192, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters, dt=stable_dt(8192)))
             e8.set_init_F(a.ic)
             e8.step(3)
             e8.sync()
@@ -259,8 +296,8 @@ def main():
             e8.sync()
             dt8 = time.perf_counter() - t0
             e8.close()
-            ref8192 = {"workload": "8192x8192 -ic %d %s, single strip (the grid bench.py --gpus N > 1 strong-scales)" % (
-                a.ic, a.dtype), "value": 8192 * 8192 * 12 / dt8, "unit": "cell-updates/s", "ms_per_step": 1e3 * dt8 / 12,
+            ref8192 = {"workload": "8192x8192 -ic %d %s dt %g, single strip (the grid bench.py --gpus N > 1 strong-scales)" % (
+                a.ic, a.dtype, stable_dt(8192)), "value": 8192 * 8192 * 12 / dt8, "unit": "cell-updates/s", "ms_per_step": 1e3 * dt8 / 12,
                 "steps": 12}
         except Exception as exc:   # e.g. not enough free HBM
             ref8192 = {"error": str(exc)}
@@ -279,13 +316,15 @@ def main():
             "vs_baseline": None,
             "dtype": a.dtype,
             "data": "synthetic (set_init_F -ic %d generated on device)" % a.ic,
-            "config": {"workload": "%dx%d -ic %d %s, %d Jacobi sweeps/step, %s" % (
-                nx, ny, a.ic, a.dtype, a.jacobi_iters, "single strip" if not dist_path else
-                "%d row strips, %d-row deep halo, per-field RCCL P2P exchange overlapped with the step" % (
-                    world, solver.halo)),
-                "nx": nx, "ny": ny, "jacobi_iters": a.jacobi_iters,
-                "arrays_per_cell_update": ARRAYS_PER_STEP if not dist_path else ARRAYS_PER_STEP + 2,
-                "bytes_per_cell_update_algorithmic": (ARRAYS_PER_STEP if not dist_path else ARRAYS_PER_STEP + 2) * esz},
+            "config": {"workload": "%dx%d -ic %d %s, dt %g, %d Jacobi sweeps/step, %s" % (
+                nx, ny, a.ic, a.dtype, dt, a.jacobi_iters, "single strip" if not dist_path else
+                "%d row strips, %d-row deep halo, per-field RCCL send/recv (%s) overlap mode %d" % (
+                    world, solver.halo, exchange, a.overlap)),
+                "nx": nx, "ny": ny, "dt": dt, "jacobi_iters": a.jacobi_iters,
+                "exchange": exchange, "overlap": a.overlap if dist_path else None,
+                "exchange_graph": (eng.comm_info()[1] == 1) if exchange == "native" else None,
+                "arrays_per_cell_update": ARRAYS_PER_STEP,
+                "bytes_per_cell_update_algorithmic": ARRAYS_PER_STEP * esz},
             # The Poisson Jacobi kernel (north star): algorithmic bytes = 3 arrays x sizeof(T) x
             # cells per launch, duration from the HIP-event pair above; `traffic` = HBM
             # bytes per launch from the committed rocprofv3 --pmc passes (profiles/jacobi_pmc.json).
@@ -295,14 +334,19 @@ def main():
                          "launches_timed": max(2, a.jacobi_sweeps_timed // 2 * 2)},
             "jacobi_fused": fused,
             "strong_scaling_reference_n1": ref8192,
-            "step_hbm_gbs_algorithmic": (ARRAYS_PER_STEP if not dist_path else ARRAYS_PER_STEP + 2) * esz * nx * ny * a.steps / elapsed / 1e9,
+            "step_hbm_gbs_algorithmic": ARRAYS_PER_STEP * esz * nx * ny * a.steps / elapsed / 1e9,
             "kernels_us_dispatch_start_to_stop": kernels_us,
             "courant_violations": violations,
         }
         if not dist_path and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, a.dtype, a.ic, a.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if dist_path:
+    if dist_path and a.exchange == "native":
+        solver.barrier()
+        with _StdoutToStderr():
+            solver.close()
+        comm.cleanup()
+    elif dist_path:
         import torch.distributed as dist
         dist.barrier()
         solver.close()

@@ -106,9 +106,17 @@ int vof_post_process_f(vof2d_handle h);             /* :452-455 */
  * kernel schedule.  rho/nu/kappa scratch is not materialised. */
 int vof_step(vof2d_handle h, int64_t nsteps);
 /* The same step split at the points where a field becomes final, for drivers that overlap the
- * halo exchange with compute (vof2d/strips.py): phase 0 = predictor + pressure solve (p final),
- * phase 1 = update_uv + set_BC (u, v final), phase 2 = VOF transport + set_BC (F final).
- * Must be called in the order 0, 1, 2; phase 0 increments istep. */
+ * halo exchange with compute (vof2d/strips.py, vof_step_exchange):
+ *   phase 0 = predictor + pressure solve + set_BC(p, F)                      -> p final
+ *   phase 1 = update_uv folded into the first FCT sweep + set_BC(u, v)       -> u, v final
+ *   phase 2 = second FCT sweep + post_process_f + set_BC(F) on the owned rows -> F final
+ * or, instead of phase 2, VOF_PHASE_TRANSPORT_EDGES (the VOF_HALO_ROWS-row bands next to a
+ * strip's interior edges, final in the twin buffer of F: what the neighbours wait for) followed by
+ * VOF_PHASE_TRANSPORT_REST (the remaining owned rows).  Order 0, 1, 2 or 0, 1, 3, 4; phase 0
+ * increments istep.  Halo rows of F are not produced by the second sweep: they are the
+ * neighbours' to send. */
+#define VOF_PHASE_TRANSPORT_EDGES 3
+#define VOF_PHASE_TRANSPORT_REST 4
 int vof_step_phase(vof2d_handle h, int32_t phase);
 int vof_get_istep(vof2d_handle h, int64_t* istep);
 int vof_set_istep(vof2d_handle h, int64_t istep);
@@ -171,6 +179,45 @@ int vof_reset_profile(vof2d_handle h);
  * handle's stream; *ms_per_sweep = elapsed / n.  p advances by n sweeps.  Uses the kernels the
  * step uses (k_jacobi_tb launches of `jacobi_tb` sweeps, k_jacobi when that parameter is 1). */
 int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep);
+/* ---- strips over RCCL (extension: the reference is single-device) ----
+ * A handle that stores a row strip (row_lo..row_hi with VOF_HALO_ROWS halo rows on each interior
+ * side of own_lo..own_hi) can run the per-step halo exchange itself: rank r of `world` owns the
+ * r-th strip counted from the left wall and trades W = VOF_HALO_ROWS(jacobi_iters) rows of F, u,
+ * v, p with ranks r-1 and r+1 by ncclSend / ncclRecv, straight from / to field memory, on a
+ * communication stream of its own.  RCCL is bound at run time (librccl.so.1; a copy already in the
+ * process, e.g. PyTorch's, is reused), so single-GPU users need no RCCL.
+ *   vof_comm_get_unique_id  on one rank; ship the VOF_COMM_ID_BYTES to the others (any transport)
+ *   vof_comm_init           collective over all ranks (ncclCommInitRank)
+ *   vof_step_exchange       nsteps x [phase 0, send/recv p, phase 1, send/recv u v, phase 2,
+ *                           send/recv F, join]: each field leaves as soon as it is final for the
+ *                           step and travels under the remaining kernels (overlap = 1).
+ *                           overlap = 0: one exchange of all four after the step; overlap = 2:
+ *                           like 1 with phase 2 split (VOF_PHASE_TRANSPORT_EDGES, send/recv F,
+ *                           VOF_PHASE_TRANSPORT_REST).  After the first step (RCCL connects on
+ *                           first use) a step and its exchanges are one hipGraph launch; if the
+ *                           RCCL at hand cannot be captured the launches stay eager.  The host
+ *                           does not block
+ *   vof_comm_exchange       one exchange of the fields in field_mask, then join (for verb-level
+ *                           drivers, e.g. the residual-terminated pressure solve)
+ * VOF_COMM_LOOPBACK (self-test on one GPU): both neighbours are the calling rank itself. */
+#define VOF_COMM_ID_BYTES 128
+#define VOF_COMM_LOOPBACK 1
+#define VOF_XCHG_F 1u
+#define VOF_XCHG_U 2u
+#define VOF_XCHG_V 4u
+#define VOF_XCHG_P 8u
+int vof_comm_get_unique_id(void* id /* VOF_COMM_ID_BYTES */);
+int vof_comm_init(vof2d_handle h, const void* id, int32_t rank, int32_t world, int32_t flags);
+int vof_comm_exchange(vof2d_handle h, uint32_t field_mask);
+int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap);
+/* max over all ranks of *value (ncclAllReduce on the compute stream, then a stream sync): the
+ * global residual of the residual-terminated pressure solve, and a barrier for timing loops. */
+int vof_comm_allreduce_max(vof2d_handle h, double* value);
+/* ncclGetVersion code of the RCCL in use (0: none) and whether vof_step_exchange replays captured
+ * graphs with this handle (verified from RCCL 2.27.7 on; older copies launch eagerly). */
+int vof_comm_info(vof2d_handle h, int32_t* rccl_version, int32_t* graph_capture);
+int vof_comm_destroy(vof2d_handle h);
+
 /* Self-test of the kernels' exact constant-denominator division (the Jacobi update p = num / ap,
  * 2dvof.py:262-264, and the / dx, / dy, / dt, / (dx*dy) of :207-232 and :327-449 are evaluated as
  * Markstein-corrected multiplications by the reciprocal): n generated (numerator, denominator)

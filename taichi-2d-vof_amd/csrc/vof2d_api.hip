@@ -6,6 +6,7 @@
 // exists here: every verb is a kernel launch.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -18,6 +19,8 @@
 #include "vof2d_kernels.h"
 
 using namespace vof;
+
+struct RcclId { char internal[VOF_COMM_ID_BYTES]; };  // ncclUniqueId, passed by value to ncclCommInitRank
 
 namespace {
 
@@ -145,7 +148,7 @@ struct vof2d_ctx {
   int fuse_momentum = 1;
   int fuse_correct = 1; // vof_step on a full domain: update_uv inside the first FCT sweep
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
-  hipGraphExec_t gphase[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // phase 0, phase 1 even / odd, phase 2 even / odd
+  hipGraphExec_t gphase[9] = {};  // phase 0, then phases 1..4 x istep parity (slot 2 * phase - 1 + parity)
   int next_phase = 0;
   void* vis = nullptr;      // scratch for the display fields (vof_get_vis_field / vof_interp_velocity)
   size_t vis_bytes = 0;
@@ -157,6 +160,18 @@ struct vof2d_ctx {
   double prof_sum_ms[16] = {};
   long prof_cnt[16] = {};
   std::map<const void*, long> occ_cache;  // resident waves per kernel function (resident_waves)
+  // strip halo exchange over RCCL (vof_comm_init): own communicator, stream and events
+  void* comm = nullptr;          // ncclComm_t
+  hipStream_t cstream = nullptr; // RCCL's kernels run here, next to the compute stream
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr};  // one per exchange of a step (graph capture forks)
+  hipGraphExec_t gxchg[2][3] = {};   // whole step + exchanges, [istep parity][overlap mode]
+  int xchg_graph = 1;                // 0 after a failed capture (or VOF2D_XCHG_GRAPH=0): eager launches
+  int64_t xchg_steps = 0;            // steps run by vof_step_exchange (the first one is always eager)
+  int64_t xchg_graph_steps = 0;      // ... of which replayed from a captured graph
+  double* d_red = nullptr;           // device scalar of vof_comm_allreduce_max
+  int comm_rank = 0, comm_world = 1;
+  int peer_lo = -1, peer_hi = -1;  // ranks owning the rows below own_lo / above own_hi (-1: wall)
   char err[512];
 };
 
@@ -251,6 +266,10 @@ int pick_rows(const vof2d_ctx* h, int ntiles) {
   if (h->rows_override > 0) return h->rows_override;
   return chunk_rows(h, ntiles, 2, 32);
 }
+inline unsigned blocks_rows(int rows, int ntiles, int R) {
+  const long waves = (long)((rows + R - 1) / R) * ntiles;
+  return (unsigned)((waves + 3) / 4);
+}
 inline unsigned blocks_for(const vof2d_ctx* h, int ntiles, int R) {
   const int rows = h->g.ihi - h->g.ilo + 1;
   const long chunks = (rows + R - 1) / R;
@@ -289,12 +308,19 @@ struct L {
     launch(h, kOther, k_init_F<T>, grid, 0, h->g, C(h), F_<T>(h, fF), F_<T>(h, fF2), ic, h->d.Lx, h->d.Ly,
            (int)(h->d.coord_cast_f32 || h->d.dtype == VOF_F32));
   }
+  // own_rows_only: the row loop skips the halo rows of a strip (wall ghost rows are never halo)
   template <int MASK>
-  static void set_bc(vof2d_ctx* h) {
+  static void set_bc(vof2d_ctx* h, bool own_rows_only = false) {
     const int nr = h->g.row_hi - h->g.row_lo + 1;
     const int n = nr > h->g.ny + 2 ? nr : h->g.ny + 2;
+    const int r0 = (own_rows_only && !h->g.wall_lo) ? h->d.own_lo : h->d.row_lo;
+    const int r1 = (own_rows_only && !h->g.wall_hi) ? h->d.own_hi : h->d.row_hi;
     launch(h, kSetBC, k_set_bc<T, MASK>, dim3((n + 255) / 256), 0, h->g, F_<T>(h, fU), F_<T>(h, fV), F_<T>(h, fF),
-           F_<T>(h, fF2), F_<T>(h, fP), F_<T>(h, fRHO));
+           F_<T>(h, fF2), F_<T>(h, fP), F_<T>(h, fRHO), r0, r1);
+  }
+  static void bc_F_cols(vof2d_ctx* h, T* F, int r0, int r1) {
+    if (r1 < r0) return;
+    launch(h, kSetBC, k_bc_F_cols<T>, dim3((r1 - r0 + 256) / 256), 0, h->g, F, r0, r1);
   }
   static void nu_rho(vof2d_ctx* h) {
     dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
@@ -368,20 +394,23 @@ struct L {
   }
   // sweeps read fld[fF], write fld[fF2]; the caller swaps the two afterwards.
   // CORR: the sweep also performs update_uv (reads u*, v*, p; writes u, v) -- see k_fct_x.
+  // rows [first, last] of the sweep's output (0, 0: all computable rows)
   template <bool POST, bool CORR>
-  static void fct_x(vof2d_ctx* h) {
+  static void fct_x(vof2d_ctx* h, int first = 0, int last = 0) {
+    if (first == 0 && last == 0) { first = h->g.ilo; last = h->g.ihi; }
     const int R = h->fctx_rows > 0 ? h->fctx_rows : chunk_rows(h, h->g.ntj, 4, 16);
-    launch(h, kFctX, k_fct_x<T, V, POST, CORR>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h),
+    launch(h, kFctX, k_fct_x<T, V, POST, CORR>, dim3(blocks_rows(last - first + 1, h->g.ntj, R)), 0, h->g, C(h),
            (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fU), F_<T>(h, fF2), R, (const T*)F_<T>(h, fUS),
-           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant);
+           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
   }
   template <bool POST, bool CORR>
-  static void fct_y(vof2d_ctx* h) {
+  static void fct_y(vof2d_ctx* h, int first = 0, int last = 0) {
+    if (first == 0 && last == 0) { first = h->g.ilo; last = h->g.ihi; }
     int R = pick_rows(h, h->nty);
     if (h->rows_override <= 0 && R > 16) R = 16;
-    launch(h, kFctY, k_fct_y<T, V, POST, CORR>, dim3(blocks_for(h, h->nty, R)), 0, h->g, C(h),
+    launch(h, kFctY, k_fct_y<T, V, POST, CORR>, dim3(blocks_rows(last - first + 1, h->nty, R)), 0, h->g, C(h),
            (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fV), F_<T>(h, fF2), R, h->nty, (const T*)F_<T>(h, fUS),
-           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant);
+           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
   }
 };
 
@@ -395,6 +424,32 @@ template <typename T, bool POST, bool CORR = false>
 void sweep_x(vof2d_ctx* h) { L<T>::template fct_x<POST, CORR>(h); swap_F(h); }
 template <typename T, bool POST, bool CORR = false>
 void sweep_y(vof2d_ctx* h) { L<T>::template fct_y<POST, CORR>(h); swap_F(h); }
+// The second sweep of a step produces the final F.  On a strip only the owned rows are produced
+// (the halo rows are the neighbours' to send), and they can be produced in two parts: the
+// VOF_HALO_ROWS-row bands next to the interior edges (what the neighbours wait for) and the rest.
+enum TransportPart { kAllOwned = 0, kEdgeBands = 1, kRest = 2 };
+template <typename T>
+void final_sweep(vof2d_ctx* h, bool along_x, int part) {
+  const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
+  const int lo = h->d.own_lo > h->g.ilo ? h->d.own_lo : h->g.ilo, hi = h->d.own_hi < h->g.ihi ? h->d.own_hi : h->g.ihi;
+  const bool band_lo = !h->g.wall_lo, band_hi = !h->g.wall_hi;
+  auto run = [&](int a, int b, bool bc) {
+    if (b < a) return;
+    if (along_x) L<T>::template fct_x<true, false>(h, a, b); else L<T>::template fct_y<true, false>(h, a, b);
+    if (bc) L<T>::bc_F_cols(h, F_<T>(h, fF2), a, b);  // rows about to be shipped carry their ghost columns
+  };
+  if (part == kAllOwned) { run(lo, hi, false); return; }
+  const int in_lo = band_lo ? lo + W : lo, in_hi = band_hi ? hi - W : hi;  // strips are >= W rows thick
+  const bool split = in_lo <= in_hi && (band_lo || band_hi);
+  if (part == kEdgeBands) {
+    if (!split) { if (band_lo || band_hi) run(lo, hi, true); return; }  // the bands meet: everything is edge
+    if (band_lo) run(lo, in_lo - 1, true);
+    if (band_hi) run(in_hi + 1, hi, true);
+  } else {
+    if (split) run(in_lo, in_hi, false);
+    else if (!band_lo && !band_hi) run(lo, hi, false);  // a full domain has no bands: the rest is everything
+  }
+}
 
 // interior copy src -> dst (only used to keep p in place for odd sweep counts)
 template <typename T>
@@ -481,9 +536,16 @@ void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false
     if (!(merge_bc && corr)) L<T>::template set_bc<BC_UV>(h);  // u, v part of :525
     if (!corr) { if (y_first) sweep_y<T, false>(h); else sweep_x<T, false>(h); }
   } else {
-    if (y_first) sweep_x<T, true>(h); else sweep_y<T, true>(h);  // second sweep, :527 fused
+    // second sweep, :527 fused: phase 2 = all owned rows; 3 = the edge bands only (then F's halo
+    // rows can leave while) 4 = the remaining rows (are produced); both write the same buffer
+    const int part = phase == 2 ? kAllOwned : (phase == 3 ? kEdgeBands : kRest);
+    final_sweep<T>(h, /*along_x=*/y_first, part);
+    if (phase == 3) return;                 // the new F stays in the twin buffer until phase 4
+    swap_F(h);
+    // F part of :528 on the rows this handle produced; a strip's halo rows arrive with the
+    // sender's ghost columns (and may be arriving right now)
     if (merge_bc && corr) L<T>::template set_bc<BC_UV | BC_F>(h);
-    else L<T>::template set_bc<BC_F>(h);    // F part of :528
+    else L<T>::template set_bc<BC_F>(h, /*own_rows_only=*/true);
   }
 }
 template <typename T>
@@ -519,11 +581,128 @@ int copy_rows_host(vof2d_ctx* h, int id, int g0, int g1, void* host, size_t nbyt
   return VOF_OK;
 }
 
+void destroy_xchg_graphs(vof2d_ctx* h);
 void destroy_graphs(vof2d_ctx* h) {
+  destroy_xchg_graphs(h);
   for (int k = 0; k < 2; ++k)
     if (h->gexec[k]) { (void)hipGraphExecDestroy(h->gexec[k]); h->gexec[k] = nullptr; }
-  for (int k = 0; k < 5; ++k)
+  for (int k = 0; k < 9; ++k)
     if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }
+}
+
+
+// ---- RCCL, bound at run time (dlopen): the library has no link-time dependency on it, and a
+// process that already carries an RCCL (PyTorch's) shares that copy instead of loading a second.
+struct Rccl {
+  void* dl = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  int version = 0;
+  char why[256] = "";
+};
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.dl ? &r : nullptr;
+  tried = true;
+  const char* cands[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  const char* forced = getenv("VOF2D_RCCL");
+  void* dl = (forced && *forced) ? dlopen(forced, RTLD_NOW | RTLD_LOCAL)
+                                 : dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // a copy the process already mapped
+  for (size_t k = 0; !dl && k < sizeof(cands) / sizeof(cands[0]); ++k) dl = dlopen(cands[k], RTLD_NOW | RTLD_LOCAL);
+  if (!dl) { snprintf(r.why, sizeof(r.why), "librccl.so.1 not found: %s", dlerror()); return nullptr; }
+#define SYM(field, name)                                                              \
+  do {                                                                                \
+    *reinterpret_cast<void**>(&r.field) = dlsym(dl, name);                            \
+    if (!r.field) { snprintf(r.why, sizeof(r.why), "RCCL lacks %s", name); dlclose(dl); return nullptr; } \
+  } while (0)
+  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+  SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
+  SYM(GetErrorString, "ncclGetErrorString"); SYM(AllReduce, "ncclAllReduce"); SYM(GetVersion, "ncclGetVersion");
+#undef SYM
+  (void)r.GetVersion(&r.version);
+  r.dl = dl;
+  return &r;
+}
+
+#define NCCLCHK(h, call)                                                                         \
+  do {                                                                                           \
+    int r_ = (call);                                                                             \
+    if (r_ != 0) {                                                                               \
+      snprintf((h)->err, sizeof((h)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call,          \
+               rccl()->GetErrorString(r_));                                                      \
+      return VOF_EHIP;                                                                           \
+    }                                                                                            \
+  } while (0)
+
+void comm_teardown(vof2d_ctx* h) {
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->cstream) (void)hipStreamSynchronize(h->cstream);
+  destroy_xchg_graphs(h);  // captured send/recv nodes hold the communicator: they go first
+  if (h->d_red) { (void)hipFree(h->d_red); h->d_red = nullptr; }
+  if (h->comm && rccl()) (void)rccl()->CommDestroy(h->comm);
+  h->comm = nullptr;
+  if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+  if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+  for (int k = 0; k < 3; ++k) {
+    if (h->ev_fork[k]) (void)hipEventDestroy(h->ev_fork[k]);
+    h->ev_fork[k] = nullptr;
+  }
+  destroy_xchg_graphs(h);
+  if (h->cstream) (void)hipStreamDestroy(h->cstream);
+  h->ev_ready = h->ev_done = nullptr;
+  h->cstream = nullptr;
+  h->peer_lo = h->peer_hi = -1;
+}
+
+// Halo exchange of the fields in `mask` with both neighbours: W = VOF_HALO_ROWS owned rows out, W
+// halo rows in, per side -- a row is `pitch` contiguous elements, so each message is one contiguous
+// block of field memory (no packing).  One RCCL group on the communication stream, ordered after
+// everything enqueued on the compute stream so far; the compute stream does not wait (comm_join).
+void destroy_xchg_graphs(vof2d_ctx* h) {
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 3; ++b)
+      if (h->gxchg[a][b]) { (void)hipGraphExecDestroy(h->gxchg[a][b]); h->gxchg[a][b] = nullptr; }
+}
+int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1) {
+  Rccl* r = rccl();
+  const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
+  const size_t row_bytes = (size_t)h->g.pitch * h->esz, bytes = (size_t)W * row_bytes;
+  hipEvent_t ready = fork >= 0 ? h->ev_fork[fork] : h->ev_ready;
+  HIPCHK(h, hipEventRecord(ready, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->cstream, ready, 0));
+  static const int ids[4] = {fF, fU, fV, fP};
+  NCCLCHK(h, r->GroupStart());
+  for (int k = 0; k < 4; ++k) {
+    if (!(mask & (1u << k))) continue;
+    // between the two transport phases the new F still lives in the twin buffer
+    char* base = reinterpret_cast<char*>(h->fld[(k == 0 && f_in_twin) ? fF2 : ids[k]]);
+    auto row = [&](int g) { return base + (size_t)(g - h->d.row_lo) * row_bytes; };
+    if (h->peer_lo >= 0) {
+      NCCLCHK(h, r->Send(row(h->d.own_lo), bytes, /*ncclInt8*/ 0, h->peer_lo, h->comm, h->cstream));
+      NCCLCHK(h, r->Recv(row(h->d.own_lo - W), bytes, 0, h->peer_lo, h->comm, h->cstream));
+    }
+    if (h->peer_hi >= 0) {
+      NCCLCHK(h, r->Send(row(h->d.own_hi - W + 1), bytes, 0, h->peer_hi, h->comm, h->cstream));
+      NCCLCHK(h, r->Recv(row(h->d.own_hi + 1), bytes, 0, h->peer_hi, h->comm, h->cstream));
+    }
+  }
+  NCCLCHK(h, r->GroupEnd());
+  return VOF_OK;
+}
+// the compute stream waits for every exchange posted so far
+int comm_join(vof2d_ctx* h) {
+  HIPCHK(h, hipEventRecord(h->ev_done, h->cstream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done, 0));
+  return VOF_OK;
 }
 
 }  // namespace
@@ -625,6 +804,7 @@ int vof_destroy(vof2d_handle h) {
     if (h->tev[k]) (void)hipEventDestroy(h->tev[k]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  comm_teardown(h);
   if (h->vis) (void)hipFree(h->vis);
   if (h->d_courant) (void)hipFree(h->d_courant);
   if (h->arena) (void)hipFree(h->arena);
@@ -676,7 +856,8 @@ int vof_update_uv(vof2d_handle h) {
 // stale: drop the graphs (they are re-captured on the next vof_step / vof_step_phase).
 static void sweep_swapped(vof2d_handle h) {
   bool any = h->gexec[0] || h->gexec[1];
-  for (int k = 0; k < 5; ++k) any = any || h->gphase[k];
+  for (int k = 0; k < 9; ++k) any = any || h->gphase[k];
+  for (int k = 0; k < 6; ++k) any = any || h->gxchg[k / 3][k % 3];
   if (!any) return;
   (void)hipStreamSynchronize(h->stream);
   destroy_graphs(h);
@@ -742,16 +923,19 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
 }
 int vof_step_phase(vof2d_handle h, int32_t phase) {
   if (!h) return VOF_EINVAL;
-  if (phase < 0 || phase > 2) return fail(h, VOF_EINVAL, "phase must be 0, 1 or 2");
-  if (phase != h->next_phase) return fail(h, VOF_ESTATE, "vof_step_phase must be called in the order 0, 1, 2");
+  if (phase < 0 || phase > 4) return fail(h, VOF_EINVAL, "phase must be 0 ... 4");
+  // order: 0, 1, then 2 or (3, 4)
+  const bool ok = phase == h->next_phase || (phase == VOF_PHASE_TRANSPORT_EDGES && h->next_phase == 2);
+  if (!ok) return fail(h, VOF_ESTATE, "vof_step_phase must be called in the order 0, 1, 2 or 0, 1, 3, 4");
   if (phase == 0) h->istep += 1;
-  h->next_phase = (phase + 1) % 3;
+  h->next_phase = (phase == 2 || phase == 4) ? 0 : phase + 1;
   const bool use_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
   if (!use_graph) {
     DISPATCH_T(h, enqueue_phase<double>(h, phase, h->istep), enqueue_phase<float>(h, phase, h->istep));
     return ensure_ok(h);
   }
   const int slot = phase == 0 ? 0 : 2 * phase - 1 + (int)(h->istep & 1);
+  bool captured_now = false;
   if (!h->gphase[slot]) {
     hipGraph_t graph = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -763,8 +947,12 @@ int vof_step_phase(vof2d_handle h, int32_t phase) {
       snprintf(h->err, sizeof(h->err), "hipGraphInstantiate: %s", hipGetErrorString(e));
       return VOF_EHIP;
     }
+    captured_now = true;
   }
   HIPCHK(h, hipGraphLaunch(h->gphase[slot], h->stream));
+  // keep the host's view of the F / twin buffers in step with what the replayed kernels did
+  // (capturing ran enqueue_phase, which swapped them itself)
+  if (!captured_now && (phase == 1 || phase == 2 || phase == 4)) swap_F(h);
   return VOF_OK;
 }
 int vof_get_istep(vof2d_handle h, int64_t* istep) {
@@ -977,6 +1165,10 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
     *value = (int64_t)v;
     return VOF_OK;
   }
+  if (!strcmp(name, "exchange_graph_steps")) {  // steps vof_step_exchange replayed from a captured graph
+    *value = h->xchg_graph_steps;
+    return VOF_OK;
+  }
   return fail(h, VOF_EINVAL, "unknown counter");
 }
 
@@ -1063,6 +1255,174 @@ int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep) {
   *ms_per_sweep = ms / (float)n;
   return ensure_ok(h);
 }
+// ---- strips over RCCL: the per-step halo exchange without leaving the library
+int vof_comm_get_unique_id(void* id) {
+  if (!id) return VOF_EINVAL;
+  Rccl* r = rccl();
+  if (!r) return VOF_ESTATE;
+  return r->GetUniqueId(id) == 0 ? VOF_OK : VOF_EHIP;
+}
+int vof_comm_init(vof2d_handle h, const void* id, int32_t rank, int32_t world, int32_t flags) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) return VOF_EINVAL;
+  if (h->comm) return fail(h, VOF_ESTATE, "vof_comm_init: the handle already has a communicator");
+  Rccl* r = rccl();
+  if (!r) return fail(h, VOF_ESTATE, "RCCL (librccl.so.1) could not be loaded");
+  const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
+  const bool lo = !h->g.wall_lo, hi = !h->g.wall_hi;  // interior edges
+  const bool loop = (flags & VOF_COMM_LOOPBACK) != 0;
+  if (lo && h->d.own_lo - W < h->d.row_lo) return fail(h, VOF_EINVAL, "fewer than VOF_HALO_ROWS rows stored below own_lo");
+  if (hi && h->d.own_hi + W > h->d.row_hi) return fail(h, VOF_EINVAL, "fewer than VOF_HALO_ROWS rows stored above own_hi");
+  if (h->d.own_hi - h->d.own_lo + 1 < W) return fail(h, VOF_EINVAL, "strip thinner than VOF_HALO_ROWS");
+  if (!loop && ((lo && rank == 0) || (hi && rank == world - 1) || (!lo && rank != 0) || (!hi && rank != world - 1)))
+    return fail(h, VOF_EINVAL, "rank does not match the strip: rank r of n owns the r-th row range from the left wall");
+  HIPCHK(h, hipSetDevice(h->device));
+  RcclId uid;
+  memcpy(&uid, id, sizeof(uid));
+  NCCLCHK(h, r->CommInitRank(&h->comm, world, uid, rank));
+  HIPCHK(h, hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+  for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork[k], hipEventDisableTiming));
+  // Capturing the send/recv groups into the step graph is verified with RCCL 2.27.7 (ROCm 7.2);
+  // 2.26.6 (the copy bundled with PyTorch 2.10 + ROCm 7.0) crashes in hipStreamEndCapture.
+  h->xchg_graph = r->version >= 22707 ? 1 : 0;
+  const char* ev = getenv("VOF2D_XCHG_GRAPH");
+  if (ev) h->xchg_graph = atoi(ev);
+  h->xchg_steps = 0;
+  h->comm_rank = rank;
+  h->comm_world = world;
+  // loopback (self-test on one GPU): both neighbours are this rank; RCCL pairs the k-th send to a
+  // peer with the k-th receive from it, so each halo receives the W owned rows next to it
+  h->peer_lo = lo ? (loop ? rank : rank - 1) : -1;
+  h->peer_hi = hi ? (loop ? rank : rank + 1) : -1;
+  return VOF_OK;
+}
+int vof_comm_allreduce_max(vof2d_handle h, double* value) {
+  if (!h || !value) return VOF_EINVAL;
+  if (!h->comm) return fail(h, VOF_ESTATE, "vof_comm_init has not been called");
+  Rccl* r = rccl();
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->d_red) HIPCHK(h, hipMalloc(&h->d_red, sizeof(double)));
+  // on the compute stream: ordered after everything enqueued so far, so it doubles as a barrier
+  HIPCHK(h, hipMemcpyAsync(h->d_red, value, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  NCCLCHK(h, r->AllReduce(h->d_red, h->d_red, 1, /*ncclFloat64*/ 8, /*ncclMax*/ 2, h->comm, h->stream));
+  HIPCHK(h, hipMemcpyAsync(value, h->d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return VOF_OK;
+}
+int vof_comm_info(vof2d_handle h, int32_t* rccl_version, int32_t* graph_capture) {
+  if (!h) return VOF_EINVAL;
+  Rccl* r = rccl();
+  if (rccl_version) *rccl_version = r ? r->version : 0;
+  if (graph_capture) *graph_capture = (h->comm && h->xchg_graph && !(h->d.flags & VOF_FLAG_NO_GRAPH)) ? 1 : 0;
+  return VOF_OK;
+}
+int vof_comm_destroy(vof2d_handle h) {
+  if (!h) return VOF_EINVAL;
+  comm_teardown(h);
+  return VOF_OK;
+}
+static unsigned field_mask_ok(uint32_t mask) { return mask != 0 && (mask & ~15u) == 0; }
+int vof_comm_exchange(vof2d_handle h, uint32_t field_mask) {
+  if (!h) return VOF_EINVAL;
+  if (!h->comm) return fail(h, VOF_ESTATE, "vof_comm_init has not been called");
+  if (!field_mask_ok(field_mask)) return fail(h, VOF_EINVAL, "field_mask: VOF_XCHG_F | _U | _V | _P");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = comm_post(h, field_mask);
+  return rc ? rc : comm_join(h);
+}
+}  // extern "C"
+namespace {
+// One step with its exchanges on (compute stream, communication stream).  mode 0: one exchange of
+// all four fields after the step; 1: each field leaves as soon as it is final (p after phase 0,
+// u, v after phase 1, F after phase 2); 2: like 1, and F's edge bands are produced first so that F
+// travels under the rest of the second sweep.  Enqueued eagerly or under stream capture.
+template <typename T>
+int enqueue_step_exchange(vof2d_ctx* h, int mode) {
+  int rc;
+  enqueue_phase<T>(h, 0, h->istep);
+  if (mode && (rc = comm_post(h, VOF_XCHG_P, false, 0))) return rc;                 // p is final
+  enqueue_phase<T>(h, 1, h->istep);
+  if (mode && (rc = comm_post(h, VOF_XCHG_U | VOF_XCHG_V, false, 1))) return rc;   // u, v are final
+  if (mode == 2) {
+    enqueue_phase<T>(h, VOF_PHASE_TRANSPORT_EDGES, h->istep);
+    if ((rc = comm_post(h, VOF_XCHG_F, /*f_in_twin=*/true, 2))) return rc;
+    enqueue_phase<T>(h, VOF_PHASE_TRANSPORT_REST, h->istep);
+  } else {
+    enqueue_phase<T>(h, 2, h->istep);
+    if ((rc = comm_post(h, mode ? VOF_XCHG_F : (VOF_XCHG_F | VOF_XCHG_U | VOF_XCHG_V | VOF_XCHG_P), false, 2))) return rc;
+  }
+  return comm_join(h);                          // halos complete before the next step
+}
+}  // namespace
+extern "C" {
+int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
+  if (!h || nsteps < 0 || overlap < 0 || overlap > 2) return VOF_EINVAL;
+  if (!h->comm) return fail(h, VOF_ESTATE, "vof_comm_init has not been called");
+  if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
+  HIPCHK(h, hipSetDevice(h->device));
+  const bool want_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
+  for (int64_t s = 0; s < nsteps; ++s) {
+    h->istep += 1;
+    const int par = (int)(h->istep & 1);
+    int rc;
+    // The first step of a communicator runs eagerly: RCCL sets its peer connections up on first
+    // use, which must not happen inside a capture.  After that the whole step -- kernels on the
+    // compute stream, the send/recv groups forked onto the communication stream, the join -- is
+    // one hipGraph per (sweep order, mode): one launch per step instead of four graph launches
+    // and three RCCL group launches (~100 us of host time each).
+    if (want_graph && h->xchg_graph && h->xchg_steps > 0) {
+      if (!h->gxchg[par][overlap]) {
+        void* keep[NFIELDS];
+        memcpy(keep, h->fld, sizeof(keep));
+        hipGraph_t graph = nullptr;
+        const bool dbg = getenv("VOF2D_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[vof2d] capturing step + exchange (parity %d, mode %d)\n", par, overlap);
+        hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed);
+        rc = VOF_OK;
+        if (e == hipSuccess) {
+          DISPATCH_T(h, rc = enqueue_step_exchange<double>(h, overlap), rc = enqueue_step_exchange<float>(h, overlap));
+          if (dbg) fprintf(stderr, "[vof2d]   enqueued (rc %d), ending capture\n", rc);
+          e = hipStreamEndCapture(h->stream, &graph);
+          if (dbg) fprintf(stderr, "[vof2d]   capture ended: %s\n", hipGetErrorString(e));
+        }
+        if (e == hipSuccess && rc == VOF_OK && graph) e = hipGraphInstantiate(&h->gxchg[par][overlap], graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess || rc != VOF_OK || !h->gxchg[par][overlap]) {
+          // this RCCL / runtime cannot capture the exchange: keep going with eager launches
+          (void)hipGetLastError();
+          memcpy(h->fld, keep, sizeof(keep));
+          h->gxchg[par][overlap] = nullptr;
+          h->xchg_graph = 0;
+          if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] exchange graph capture failed (%s / %s): eager\n", hipGetErrorString(e), h->err);
+        }
+      }
+      if (h->gxchg[par][overlap]) {
+        HIPCHK(h, hipGraphLaunch(h->gxchg[par][overlap], h->stream));
+        h->xchg_steps += 1;
+        h->xchg_graph_steps += 1;
+        continue;
+      }
+    }
+    h->istep -= 1;  // vof_step_phase(0) advances it
+    if ((rc = vof_step_phase(h, 0))) return rc;
+    if (overlap && (rc = comm_post(h, VOF_XCHG_P))) return rc;
+    if ((rc = vof_step_phase(h, 1))) return rc;
+    if (overlap && (rc = comm_post(h, VOF_XCHG_U | VOF_XCHG_V))) return rc;
+    if (overlap == 2) {
+      if ((rc = vof_step_phase(h, VOF_PHASE_TRANSPORT_EDGES))) return rc;
+      if ((rc = comm_post(h, VOF_XCHG_F, /*f_in_twin=*/true))) return rc;
+      if ((rc = vof_step_phase(h, VOF_PHASE_TRANSPORT_REST))) return rc;
+    } else {
+      if ((rc = vof_step_phase(h, 2))) return rc;
+      if ((rc = comm_post(h, overlap ? VOF_XCHG_F : (VOF_XCHG_F | VOF_XCHG_U | VOF_XCHG_V | VOF_XCHG_P)))) return rc;
+    }
+    if ((rc = comm_join(h))) return rc;
+    h->xchg_steps += 1;
+  }
+  return VOF_OK;
+}
+
 // ---- self-test of the exact constant-denominator division (vof2d_kernels.h div_by_const) against
 // the hardware IEEE division, on adversarial numerators: subnormal quotients at and next to the
 // midpoints of the subnormal grid (the double-rounding case), tiny / huge / special values.

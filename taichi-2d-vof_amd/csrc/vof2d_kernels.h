@@ -217,13 +217,15 @@ __global__ __launch_bounds__(256) void k_init_F(Geom g, Consts<T> c, T* __restri
 enum : int { BC_UV = 1, BC_F = 2, BC_P = 4, BC_RHO = 8, BC_ALL = 7 };
 template <typename T, int MASK>
 __global__ __launch_bounds__(256) void k_set_bc(Geom g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ F,
-                                                 T* __restrict__ F2, T* __restrict__ p, T* __restrict__ rho) {
+                                                 T* __restrict__ F2, T* __restrict__ p, T* __restrict__ rho,
+                                                 int r0, int r1) {
   constexpr bool UV = MASK & BC_UV, DF = MASK & BC_F, DP = MASK & BC_P, STORED = MASK & BC_RHO;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ny = g.ny, nx = g.nx;
-  // loop 1: row i
+  // loop 1: row i, restricted to [r0, r1] (a strip leaves the halo rows of a field whose exchange
+  // is in flight to the sender, who ships its rows with their ghost columns)
   const int i = g.row_lo + t;
-  if (i <= g.row_hi) {
+  if (i <= g.row_hi && i >= r0 && i <= r1) {
     const bool wall_row = (g.wall_lo && i == 1) || (g.wall_hi && i == nx + 1);    // u zeroed by loop 2
     const bool ghost_row = (g.wall_lo && i == 0) || (g.wall_hi && i == nx + 1);   // F,p,v,rho from loop 2
     const size_t a0 = at(g, i, 0), a1 = at(g, i, 1), b0 = at(g, i, ny), b1 = at(g, i, ny + 1);
@@ -283,6 +285,17 @@ __global__ __launch_bounds__(256) void k_set_bc(Geom g, T* __restrict__ u, T* __
       if (STORED) rho[at(g, nx + 1, j)] = rho[at(g, nx, jj)];
     }
   }
+}
+
+
+// ghost columns of one F buffer for rows [r0, r1]: the F part of set_BC's loop 1 (:162-174) for the
+// edge bands of a strip, whose final F leaves for the neighbour before the rest of the rows exist
+template <typename T>
+__global__ __launch_bounds__(256) void k_bc_F_cols(Geom g, T* __restrict__ F, int r0, int r1) {
+  const int i = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > r1) return;
+  F[at(g, i, 0)] = F[at(g, i, 1)];
+  F[at(g, i, g.ny + 1)] = F[at(g, i, g.ny)];
 }
 
 // ------------------------------------------------------------------ cal_nu_rho
@@ -1148,9 +1161,10 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
                                                 const T* __restrict__ u, T* __restrict__ Fn, int R,
                                                 const T* __restrict__ us, const T* __restrict__ vs,
                                                 const T* __restrict__ p, T* __restrict__ Uo, T* __restrict__ Vo,
-                                                unsigned long long* __restrict__ courant) {
+                                                unsigned long long* __restrict__ courant, int rfirst, int rlast) {
+  // rows [rfirst, rlast] (within [ilo, ihi]) are produced; the sweep's domain stays [ilo, ihi]
   int j0, ra, rb;
-  if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
+  if (!wave_tile<V>(g, rfirst, rlast, R, j0, ra, rb)) return;
   const int ilo = g.ilo, ihi = g.ihi;
   // state, indexed relative to the newest row r
   T F1[V];                       // F[r-1]
@@ -1320,16 +1334,16 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
                                                 const T* __restrict__ v, T* __restrict__ Fn, int R, int nty,
                                                 const T* __restrict__ us, const T* __restrict__ vs,
                                                 const T* __restrict__ p, T* __restrict__ Uo, T* __restrict__ Vo,
-                                                unsigned long long* __restrict__ courant) {
+                                                unsigned long long* __restrict__ courant, int rfirst, int rlast) {
   constexpr int W = 64 * V, STRIDE = W - 8;
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR: rows are wave-uniform
   const int lane = threadIdx.x & 63;
   const int tj = wave % nty, ch = wave / nty;
   const int c0 = -3 + tj * STRIDE;
   const int j0 = c0 + lane * V;
-  const int ra = g.ilo + ch * R;
-  if (ra > g.ihi) return;  // wave-uniform
-  const int rb = ra + R - 1 < g.ihi ? ra + R - 1 : g.ihi;
+  const int ra = rfirst + ch * R;
+  if (ra > rlast) return;  // wave-uniform
+  const int rb = ra + R - 1 < rlast ? ra + R - 1 : rlast;
   const int ny = g.ny;
   const int jlo = c0 + 4 > 1 ? c0 + 4 : 1;
   const int jhi = c0 + W - 5 < ny ? c0 + W - 5 : ny;

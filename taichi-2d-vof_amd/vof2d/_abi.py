@@ -11,6 +11,8 @@ VOF_ABI_VERSION = 1
 VOF_F64, VOF_F32 = 0, 1
 VOF_OK, VOF_EINVAL, VOF_EHIP, VOF_ENOMEM, VOF_ESTATE = 0, -1, -2, -3, -4
 VOF_FLAG_NO_GRAPH = 1
+VOF_COMM_ID_BYTES, VOF_COMM_LOOPBACK = 128, 1
+VOF_XCHG_F, VOF_XCHG_U, VOF_XCHG_V, VOF_XCHG_P = 1, 2, 4, 8
 
 ERRNAMES = {VOF_EINVAL: "VOF_EINVAL", VOF_EHIP: "VOF_EHIP", VOF_ENOMEM: "VOF_ENOMEM",
             VOF_ESTATE: "VOF_ESTATE"}
@@ -86,6 +88,13 @@ SIGNATURES = {
     "profile_steps": (C.c_int, [H, _i64]),
     "get_profile": (C.c_int, [H, _str, C.POINTER(_dbl), C.POINTER(_i64)]),
     "reset_profile": (C.c_int, [H]),
+    "comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "comm_init": (C.c_int, [H, C.c_void_p, _i32, _i32, _i32]),
+    "comm_exchange": (C.c_int, [H, C.c_uint32]),
+    "step_exchange": (C.c_int, [H, _i64, _i32]),
+    "comm_allreduce_max": (C.c_int, [H, C.POINTER(_dbl)]),
+    "comm_info": (C.c_int, [H, C.POINTER(_i32), C.POINTER(_i32)]),
+    "comm_destroy": (C.c_int, [H]),
     "selftest_division": (C.c_int, [_i32, _i64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "last_error": (C.c_char_p, [H]),
     "backend": (C.c_char_p, []),
@@ -94,7 +103,8 @@ SIGNATURES = {
 
 # entry points that only the GPU library implements (timing / profiling on a HIP stream)
 GPU_ONLY = ("timer_start", "timer_stop", "time_jacobi", "profile_steps", "get_profile", "reset_profile",
-            "selftest_division")
+            "selftest_division", "comm_get_unique_id", "comm_init", "comm_exchange", "step_exchange", "comm_destroy",
+            "comm_allreduce_max", "comm_info")
 
 
 class Api:

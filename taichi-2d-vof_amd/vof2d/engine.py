@@ -210,6 +210,33 @@ class Engine:
         return v.value
 
     # -- sync / timing ----------------------------------------------------------
+    # -- strips over RCCL, inside the library (include/vof2d.h "strips over RCCL") ------
+    def comm_init(self, uid, rank, world, loopback=False):
+        buf = C.create_string_buffer(bytes(uid), _abi.VOF_COMM_ID_BYTES)
+        self._ck(self.api.comm_init(self._h, buf, int(rank), int(world),
+                                    _abi.VOF_COMM_LOOPBACK if loopback else 0), "comm_init")
+
+    def comm_exchange(self, mask):
+        self._ck(self.api.comm_exchange(self._h, int(mask)), "comm_exchange")
+
+    def step_exchange(self, nsteps=1, overlap=1):
+        """overlap: 0 = one exchange after the step, 1 = per field as soon as final, 2 = 1 + F's edge bands first."""
+        self._ck(self.api.step_exchange(self._h, int(nsteps), int(overlap)), "step_exchange")
+
+    def comm_allreduce_max(self, value):
+        v = C.c_double(float(value))
+        self._ck(self.api.comm_allreduce_max(self._h, C.byref(v)), "comm_allreduce_max")
+        return v.value
+
+    def comm_info(self):
+        """(RCCL version code, 1 if step_exchange replays captured graphs)."""
+        ver, gr = C.c_int32(), C.c_int32()
+        self._ck(self.api.comm_info(self._h, C.byref(ver), C.byref(gr)), "comm_info")
+        return ver.value, gr.value
+
+    def comm_destroy(self):
+        self._ck(self.api.comm_destroy(self._h), "comm_destroy")
+
     def sync(self):
         self._ck(self.api.sync(self._h), "sync")
 
@@ -249,4 +276,13 @@ def selftest_division(api, dtype, n, seed):
     if rc != 0:
         raise VofError("vof_selftest_division failed: %s" % _abi.ERRNAMES.get(rc, rc))
     return a, b, q
+
+
+def comm_unique_id(api):
+    """vof_comm_get_unique_id: the VOF_COMM_ID_BYTES one rank creates and every rank passes to comm_init."""
+    buf = C.create_string_buffer(_abi.VOF_COMM_ID_BYTES)
+    rc = api.comm_get_unique_id(buf)
+    if rc != 0:
+        raise VofError("vof_comm_get_unique_id failed: %s (is librccl.so.1 loadable?)" % _abi.ERRNAMES.get(rc, rc))
+    return buf.raw
 

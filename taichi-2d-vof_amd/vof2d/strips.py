@@ -51,13 +51,19 @@ class _DevArray:
 
 
 class StripSolver:
-    """One rank's strip + the per-step halo exchange."""
+    """One rank's strip + the per-step halo exchange.
+
+    exchange: who moves the halos.  "native" = the library's own RCCL communicator
+    (vof_step_exchange: the whole step loop is one C call, one hipGraph launch per step);
+    "torch" = torch.distributed P2P on tensors aliasing the field memory (what the CPU / gloo tests
+    drive); "auto" = native on the GPU, torch otherwise.
+    comm: a `comms.TorchComm` / `comms.EnvComm`; default: TorchComm over `dist` (torch.distributed).
+    With an EnvComm and the native exchange the process never imports torch."""
 
     def __init__(self, nx, ny, dtype="f64", ic=1, coord_cast="f32", jacobi_iters=10, rank=0, world=1,
-                 device=None, api=None, dist=None, **consts):
-        import torch
-        self.torch = torch
-        self.dist = dist if dist is not None else (torch.distributed if world > 1 else None)
+                 device=None, api=None, dist=None, exchange="auto", comm=None, **consts):
+        if exchange not in ("auto", "native", "torch"):
+            raise ValueError("exchange must be 'auto', 'native' or 'torch'")
         if api is None:
             from ._lib import hip_api
             api = hip_api()
@@ -71,24 +77,70 @@ class StripSolver:
             raise ValueError("strips of %d rows are thinner than the %d-row halo" % (nx // world, self.halo))
         self.own = parts[rank]
         self.rows = stored_rows(nx, self.own, self.halo)
+        from .comms import EnvComm, TorchComm
+        torch_free = isinstance(comm, EnvComm)
+        if torch_free and world > 1 and not (self.on_gpu and exchange in ("auto", "native")):
+            raise ValueError("an EnvComm carries only the native RCCL exchange (GPU library)")
+        self.torch = self.dist = self.stream = self.device = None
         stream_ptr = None
-        self.stream = None
-        if self.on_gpu:
-            dev = torch.device("cuda", device if device is not None else 0)
-            torch.cuda.set_device(dev)
-            # a dedicated non-default stream: hipGraph capture is illegal on the legacy stream, and
-            # torch.distributed orders its RCCL work against the *current* stream
-            self.stream = torch.cuda.Stream(device=dev)
-            stream_ptr = self.stream.cuda_stream
-            self.device = dev
+        if not torch_free:
+            import torch
+            self.torch = torch
+            self.dist = dist if dist is not None else (torch.distributed if world > 1 else None)
+            if self.on_gpu:
+                dev = torch.device("cuda", device if device is not None else 0)
+                torch.cuda.set_device(dev)
+                # a dedicated non-default stream: hipGraph capture is illegal on the legacy stream, and
+                # torch.distributed orders its RCCL work against the *current* stream
+                self.stream = torch.cuda.Stream(device=dev)
+                stream_ptr = self.stream.cuda_stream
+                self.device = dev
+        self.comm = comm if comm is not None else (TorchComm(self.dist, rank, world, self.device) if world > 1 else None)
         desc = make_desc(api, nx, ny, dtype, coord_cast, rows=self.rows, own=self.own,
-                         jacobi_iters=jacobi_iters, device=(device if device is not None else -1) if self.on_gpu else -1,
+                         jacobi_iters=jacobi_iters, device=(device if device is not None else 0) if self.on_gpu else -1,
                          **consts)
-        self.eng = Engine(api, desc, stream=stream_ptr)
+        self.eng = Engine(api, desc, stream=stream_ptr)   # no stream given: the library creates its own
         self.eng.set_init_F(ic)
         self._views = {}
         self._ops = {}
-        self._build_views()
+        self.exchange_kind = "torch"
+        if world > 1 and self.on_gpu and exchange in ("auto", "native"):
+            self._native_comm_init(strict=(exchange == "native" or torch_free))
+        if self.exchange_kind == "torch" and not torch_free:
+            self._build_views()
+
+    def _native_comm_init(self, strict):
+        """One RCCL communicator per strip handle; its unique id travels over `self.comm`.  With a
+        TorchComm every rank ends up in the same mode: failures are agreed on before committing."""
+        import sys
+        from .comms import TorchComm
+        from .engine import comm_unique_id, VofError
+        uid, err, ok = None, None, 0
+        if self.rank == 0:
+            try:
+                uid = comm_unique_id(self.api)
+            except VofError as e:
+                err = e
+        uid = self.comm.broadcast_bytes(uid)
+        if uid is not None:
+            try:
+                self.eng.comm_init(uid, self.rank, self.world)
+                ok = 1
+            except VofError as e:
+                err = e
+        if isinstance(self.comm, TorchComm):
+            ok_all = -self.comm.allreduce_max(-ok)   # min over ranks
+        else:
+            ok_all = ok                              # ncclCommInitRank is collective: all or none
+        if ok_all >= 1:
+            self.exchange_kind = "native"
+            return
+        if ok:
+            self.eng.comm_destroy()
+        if strict:
+            raise RuntimeError("native RCCL exchange unavailable on some rank: %s" % (err,))
+        if self.rank == 0:
+            print("[vof2d] native RCCL exchange unavailable (%s); using torch.distributed P2P" % (err,), file=sys.stderr)
 
     # -- zero-copy tensor views of the exchanged fields -----------------------------
     def _build_views(self):
@@ -148,12 +200,16 @@ class StripSolver:
         """Refresh the halo rows of `fields` from both neighbours and wait for them."""
         if self.world == 1:
             return
+        if self.exchange_kind == "native":
+            bit = {"F": _abi.VOF_XCHG_F, "u": _abi.VOF_XCHG_U, "v": _abi.VOF_XCHG_V, "p": _abi.VOF_XCHG_P}
+            self.eng.comm_exchange(sum(bit[f] for f in fields))
+            return
         for w in self._exchange_async(fields):
             w.wait()
 
     def _ctx(self):
         import contextlib
-        return self.torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def step(self, nsteps=1, overlap=True):
         """nsteps time steps.  With overlap (default) each field's halo is shipped as soon as the
@@ -164,6 +220,9 @@ class StripSolver:
         overwritten with the identical value (rows inside this rank's still-valid region) or lies
         in the invalid fringe, so owned rows are unaffected; no kernel of a later phase writes a
         field whose exchange is in flight (DESIGN.md "strips")."""
+        if self.world > 1 and self.exchange_kind == "native":
+            self.eng.step_exchange(nsteps, int(overlap))   # the whole loop in the library
+            return
         with self._ctx():
             for _ in range(nsteps):
                 if self.world == 1:
@@ -184,7 +243,7 @@ class StripSolver:
     def solve_p_residual(self, tol, max_iters, check_every=10):
         """Extension: Jacobi until the global max|p_new - p| <= tol (all-reduce MAX over ranks).
         Sweeps between checks use 1-row halos refreshed by `exchange` of p only when world > 1."""
-        torch, done, res = self.torch, 0, float("inf")
+        done, res = 0, float("inf")
         first = True
         with self._ctx():
             while done < max_iters:
@@ -194,9 +253,7 @@ class StripSolver:
                 first = False
                 done += n
                 if self.world > 1:
-                    t = torch.tensor([res], dtype=torch.float64, device=self.device if self.on_gpu else "cpu")
-                    self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-                    res = float(t.item())
+                    res = self.comm.allreduce_max(res, self.eng)
                     self.exchange(("p",))
                 if res <= tol:
                     break
@@ -216,9 +273,13 @@ class StripSolver:
         mine = self.owned(name)
         if self.world == 1:
             return mine
-        parts = [None] * self.world if self.rank == 0 else None
-        self.dist.gather_object(mine, parts, dst=0)
+        parts = self.comm.gather_object(mine)
         return np.concatenate(parts, axis=0) if self.rank == 0 else None
+
+    def barrier(self):
+        if self.world > 1:
+            self.eng.sync()
+            self.comm.barrier(self.eng)
 
     def close(self):
         self.eng.close()

@@ -2,6 +2,7 @@
 torch.distributed batch_isend_irecv).  The compute engine is the CPU oracle behind the same C ABI;
 what is under test is the host logic the GPU path shares: partitioning, halo geometry, the
 zero-copy row views, the exchange schedule and the residual all-reduce."""
+import os
 import socket
 
 import numpy as np
@@ -53,3 +54,31 @@ def test_strips_equal_single_domain(oracle_api, tmp_path, nx, ny, ic, dtype, wor
     it, res = ref.solve_p_residual(1e-9, 40, 10)
     assert int(z["it"]) == it and float(z["res"]) == res
     assert same(z["p_after"][1:-1], ref.get("p")[1:-1])
+
+
+def _envcomm_worker(rank, world, rdzv, out):
+    from vof2d.comms import EnvComm
+    c = EnvComm(rank, world, rank, rdzv_dir=rdzv, timeout=60)
+    uid = c.broadcast_bytes(b"\x01" * 128 if rank == 0 else None)
+    second = c.broadcast_bytes(b"two" if rank == 0 else None)
+    parts = c.gather_object({"rank": rank, "rows": np.full((2, 3), rank)})
+    with open(os.path.join(out, "r%d" % rank), "w") as f:
+        f.write("%d %s %s" % (len(uid), second.decode(), "none" if parts is None else
+                              ",".join(str(int(p["rows"].sum())) for p in parts)))
+
+
+def test_envcomm_file_rendezvous(tmp_path):
+    """The torch-free carrier of bench.py's N > 1 path: bytes from rank 0 reach every rank through
+    the rendezvous directory, objects gather on rank 0 (3 processes, no torch.distributed)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    rdzv, out = str(tmp_path / "rdzv"), str(tmp_path)
+    procs = [ctx.Process(target=_envcomm_worker, args=(r, 3, rdzv, out)) for r in (2, 1, 0)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert open(os.path.join(out, "r0")).read() == "128 two 0,6,12"
+    assert open(os.path.join(out, "r1")).read() == "128 two none"
+    assert open(os.path.join(out, "r2")).read() == "128 two none"
