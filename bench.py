@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--jacobi-sweeps-timed", type=int, default=200)
     ap.add_argument("--jacobi-iters", type=int, default=10, help="sweeps per step (reference: 10, 2dvof.py:521)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="skip the single-GPU 8192^2 leg (strong_scaling_reference_n1); used for the rocprofv3 "
+                         "profiles, whose per-kernel averages must come from one grid size")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed/StripSolver code path even with one rank (self-test)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -284,7 +287,7 @@ def main():
     # The N > 1 runs strong-scale 8192^2; give the single-GPU figure for that grid too, so the
     # scaling series has its own N = 1 point (only when the workload was not overridden).
     ref8192 = None
-    if not dist_path and not a.nx and rank == 0:
+    if not dist_path and not a.nx and rank == 0 and not a.no_scaling_reference:
         try:
             from vof2d.engine import Engine as _E2, make_desc as _md2
             e8 = _E2(api, _md2(api, 8192, 8192, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters, dt=stable_dt(8192)))
