@@ -195,15 +195,24 @@ def main():
         eng.sync()
         elapsed = time.perf_counter() - t0
         solver = None
-    elif a.exchange == "native":
+    native_ok = False
+    if dist_path and a.exchange == "native":
         # one process per GPU, still no torch: rank / world from the launcher's environment, the
         # library's own RCCL communicator for halos, barrier and the max over ranks
         from vof2d.comms import EnvComm
         from vof2d.strips import StripSolver
-        comm = EnvComm(rank, world, local)
+        try:
+            comm = EnvComm(rank, world, local)
+            with _StdoutToStderr():
+                solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local,
+                                     jacobi_iters=a.jacobi_iters, comm=comm, exchange="native" if world > 1 else "auto", dt=dt)
+            native_ok = True
+        except Exception as exc:   # e.g. no loadable RCCL: symmetric on all ranks -> the torch carrier
+            print("[bench] native RCCL exchange unavailable (%r); falling back to torch.distributed" % (exc,), file=sys.stderr)
+    if not dist_path:
+        pass
+    elif native_ok:
         with _StdoutToStderr():
-            solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local,
-                                 jacobi_iters=a.jacobi_iters, comm=comm, exchange="native" if world > 1 else "auto", dt=dt)
             eng = solver.eng
             solver.step(a.warmup, overlap=a.overlap)
             eng.sync()
@@ -344,7 +353,7 @@ def main():
         if not dist_path and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, a.dtype, a.ic, a.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if dist_path and a.exchange == "native":
+    if dist_path and native_ok:
         solver.barrier()
         with _StdoutToStderr():
             solver.close()
