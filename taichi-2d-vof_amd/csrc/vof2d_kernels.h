@@ -191,6 +191,25 @@ __device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
   return res;
 }
 
+// V quotients with ONE branch: all fast forms first (their instruction streams interleave), then a
+// single test whether any numerator left the fast window (tiny, zero, NaN), and only then the
+// full routine.  With a branch per quotient the compiler cannot overlap the dependent fma chains
+// of a lane's V cells.
+template <typename T, int V>
+__device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], const T (&b)[V], const T (&y)[V]) {
+  bool odd = false;
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const T q0 = a[q] * y[q];
+    res[q] = dfma<T>(dfma<T>(-b[q], q0, a[q]), y[q], q0);
+    odd = odd || !(dabs<T>(a[q]) >= DivLimits<T>::lo);
+  }
+  if (odd) {
+#pragma unroll
+    for (int q = 0; q < V; ++q) res[q] = div_by_const<T>(a[q], b[q], y[q]);
+  }
+}
+
 template <int N> struct IC { static constexpr int value = N; };
 
 // ------------------------------------------------------------------ init
@@ -1025,23 +1044,26 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
       const T ae = i != nx ? c.dxi2 : (T)0.0;
       const T aw = i != 1 ? c.dxi2 : (T)0.0;
       const int slot = ((U + 1 - s) % 6 + 6) % 6;  // constant after unrolling
+      T num[V];
 #pragma unroll
       for (int q = 0; q < V; ++q) {
         const T N = q == V - 1 ? sr : ring[s - 1][kC][q + 1];
         const T S = q == 0 ? sl : ring[s - 1][kC][q - 1];
-        T num;
         if (SQ && s > 1)  // inputs of stages 2.. are products; stage 1 reads values of p from memory
-          num = rq[slot][q] - ring[s - 1][kE][q] - ring[s - 1][kM][q] - N - S;
+          num[q] = rq[slot][q] - ring[s - 1][kE][q] - ring[s - 1][kM][q] - N - S;
         else
-          num = rq[slot][q] - ae * ring[s - 1][kE][q] - aw * ring[s - 1][kM][q] - an[q] * N - as_[q] * S;
-        if (edge) {  // wave-uniform: first / last interior row has its own ap
+          num[q] = rq[slot][q] - ae * ring[s - 1][kE][q] - aw * ring[s - 1][kM][q] - an[q] * N - as_[q] * S;
+      }
+      if (edge) {  // wave-uniform: first / last interior row has its own ap
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
           const T ap = (T)-1.0 * (ae + aw + an[q] + as_[q]);
-          T o = num / ap;
+          T o = num[q] / ap;
           if (SQ && ((j0 + q) < 1 || (j0 + q) > ny)) o = (T)0;  // same zero the interior rows produce
           carry[q] = o;
-        } else {
-          carry[q] = div_by_const<T>(num, apI[q], yI[q]);
         }
+      } else {
+        div_by_const_v<T, V>(carry, num, apI, yI);
       }
       if (s == 1 && t < t1) {
         // ring[0][kM] (row t-2) is dead now: prefetch row t+1 into it; rhs row t into the free slot
