@@ -195,19 +195,36 @@ __device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
 // single test whether any numerator left the fast window (tiny, zero, NaN), and only then the
 // full routine.  With a branch per quotient the compiler cannot overlap the dependent fma chains
 // of a lane's V cells.
-template <typename T, int V>
+template <typename T, int V, bool SMALL_B = false>
 __device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], const T (&b)[V], const T (&y)[V]) {
   bool odd = false;
 #pragma unroll
   for (int q = 0; q < V; ++q) {
     const T q0 = a[q] * y[q];
     res[q] = dfma<T>(dfma<T>(-b[q], q0, a[q]), y[q], q0);
-    odd = odd || !(dabs<T>(a[q]) >= DivLimits<T>::lo);
+    const T aa = dabs<T>(a[q]);
+    odd = odd || !(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi));
   }
   if (odd) {
+    // exact zeros (whole regions before the pressure front arrives, or away from the interface)
+    // are already right: the fast form returns the signed zero of a * y
+    bool nonzero = false;
 #pragma unroll
-    for (int q = 0; q < V; ++q) res[q] = div_by_const<T>(a[q], b[q], y[q]);
+    for (int q = 0; q < V; ++q) {
+      const T aa = dabs<T>(a[q]);
+      nonzero = nonzero || (a[q] != (T)0 && (!(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi))));
+    }
+    if (nonzero) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) res[q] = div_by_const<T, SMALL_B>(a[q], b[q], y[q]);
+    }
   }
+}
+// a / b for a numerator known to lie inside the fast window (e.g. a density): no test at all
+template <typename T>
+__device__ __forceinline__ T div_by_const_inrange(T a, T b, T y) {
+  const T q0 = a * y;
+  return dfma<T>(dfma<T>(-b, q0, a), y, q0);
 }
 
 template <int N> struct IC { static constexpr int value = N; };
@@ -749,12 +766,16 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
       const T k00 = k2[q], km0 = k3[q], k0m = q == 0 ? kl : k2[q - 1];
       const T rho00 = rho2[q], rhom0 = rho3[q], rho0m = q == 0 ? rho2l : rho2[q - 1], nu00 = nu_of(c, F00);
       T ou, ov;
+      // the two surface-tension quotients (:213, :225) share one range test
+      const T fnum[2] = {-c.sigma * (F00 - Fm0) * ((k00 + km0) / (T)2.0), -c.sigma * (F00 - F0m) * ((k00 + k0m) / (T)2.0)};
+      const T fden[2] = {c.dx, c.dy}, finv[2] = {c.inv_dx, c.inv_dy};
+      T fk[2];
+      div_by_const_v<T, 2, true>(fk, fnum, fden, finv);
       {
         T v_here = (T)0.25 * (vm0 + vmp + v00 + v0p);
         T dudx = upwind_diff<T>(u00 > 0, u00, um0, up0) * dxi;      // (u00-um0)*dxi or (up0-u00)*dxi
         T dudy = upwind_diff<T>(v_here > 0, u00, u0m, u0p) * dyi;
-        T kappa_ave = (k00 + km0) / (T)2.0;
-        T fx_kappa = div_by_const<T, true>(-c.sigma * (F00 - Fm0) * kappa_ave, c.dx, c.inv_dx);
+        T fx_kappa = fk[0];
         ou = (u00 + dt * (nu00 * (um0 - (T)2 * u00 + up0) * dxi2 + nu00 * (u0m - (T)2 * u00 + u0p) * dyi2 -
                           u00 * dudx - v_here * dudy + c.gx + div_or_zero<T>(fx_kappa * (T)2, rho00 + rhom0)));
       }
@@ -762,8 +783,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
         T u_here = (T)0.25 * (u0m + u00 + upm + up0);
         T dvdx = upwind_diff<T>(u_here > 0, v00, vm0, vp0) * dxi;
         T dvdy = upwind_diff<T>(v00 > 0, v00, v0m, v0p) * dyi;
-        T kappa_ave = (k00 + k0m) / (T)2.0;
-        T fy_kappa = div_by_const<T, true>(-c.sigma * (F00 - F0m) * kappa_ave, c.dy, c.inv_dy);
+        T fy_kappa = fk[1];
         ov = (v00 + dt * (nu00 * (vm0 - (T)2 * v00 + vp0) * dxi2 + nu00 * (v0m - (T)2 * v00 + v0p) * dyi2 -
                           u_here * dvdx - v00 * dvdy + c.gy + div_or_zero<T>(fy_kappa * (T)2, rho00 + rho0m)));
       }
@@ -783,7 +803,8 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
 #pragma unroll
       for (int q = 0; q < V; ++q) {
         const T vright = q == V - 1 ? vsr : vs3[q + 1];
-        out[q] = div_by_const<T, true>(rho3[q], c.dt, c.inv_dt) *
+        // rho lies in [rho_g, rho_l] (var clamps F, :192-196): always inside the fast window
+        out[q] = div_by_const_inrange<T>(rho3[q], c.dt, c.inv_dt) *
                  ((us2[q] - us3[q]) * c.dxi + (vright - vs3[q]) * c.dyi);
       }
       store_s<T, V>(rhs + at(g, i3, j0), out, j0, jlo, jhi);
