@@ -756,36 +756,51 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
 #pragma unroll
     for (int q = 0; q < V; ++q) rho2[q] = rho_of(c, F2.c[q]);
     const T rho2l = rho_of(c, F2.l);
+    // Surface tension (:213-214, :225-226): force = (-sigma * dF * kappa_ave / dx) * 2 / (rho + rho').
+    // Away from the interface dF or kappa_ave is an exact zero and so is the force; one wave-level
+    // test covers the 2 V quotient pairs of the lane, and the exact divisions run only behind it.
+    T fxf[V], fyf[V];
+    bool any_force = false;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const T F00 = F2.c[q], Fm0 = F3c[q], F0m = left_of(F2, q);
+      const T k00 = k2[q], km0 = k3[q], k0m = q == 0 ? kl : k2[q - 1];
+      fxf[q] = -c.sigma * (F00 - Fm0) * ((k00 + km0) / (T)2.0);
+      fyf[q] = -c.sigma * (F00 - F0m) * ((k00 + k0m) / (T)2.0);
+      any_force = any_force || fxf[q] != (T)0 || fyf[q] != (T)0;
+    }
+    if (any_force) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const T rho00 = rho2[q], rhom0 = rho3[q], rho0m = q == 0 ? rho2l : rho2[q - 1];
+        const T fnum[2] = {fxf[q], fyf[q]}, fden[2] = {c.dx, c.dy}, finv[2] = {c.inv_dx, c.inv_dy};
+        T fk[2];
+        div_by_const_v<T, 2, true>(fk, fnum, fden, finv);
+        fxf[q] = div_or_zero<T>(fk[0] * (T)2, rho00 + rhom0);
+        fyf[q] = div_or_zero<T>(fk[1] * (T)2, rho00 + rho0m);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       const T u00 = u2.c[q], um0 = u3.c[q], up0 = u1.c[q], u0m = left_of(u2, q), u0p = right_of(u2, q);
       const T upm = left_of(u1, q);
       const T v00 = v2.c[q], vm0 = v3.c[q], vp0 = v1.c[q], v0m = left_of(v2, q), v0p = right_of(v2, q);
       const T vmp = right_of(v3, q);
-      const T F00 = F2.c[q], Fm0 = F3c[q], F0m = left_of(F2, q);
-      const T k00 = k2[q], km0 = k3[q], k0m = q == 0 ? kl : k2[q - 1];
-      const T rho00 = rho2[q], rhom0 = rho3[q], rho0m = q == 0 ? rho2l : rho2[q - 1], nu00 = nu_of(c, F00);
+      const T nu00 = nu_of(c, F2.c[q]);
       T ou, ov;
-      // the two surface-tension quotients (:213, :225) share one range test
-      const T fnum[2] = {-c.sigma * (F00 - Fm0) * ((k00 + km0) / (T)2.0), -c.sigma * (F00 - F0m) * ((k00 + k0m) / (T)2.0)};
-      const T fden[2] = {c.dx, c.dy}, finv[2] = {c.inv_dx, c.inv_dy};
-      T fk[2];
-      div_by_const_v<T, 2, true>(fk, fnum, fden, finv);
       {
         T v_here = (T)0.25 * (vm0 + vmp + v00 + v0p);
         T dudx = upwind_diff<T>(u00 > 0, u00, um0, up0) * dxi;      // (u00-um0)*dxi or (up0-u00)*dxi
         T dudy = upwind_diff<T>(v_here > 0, u00, u0m, u0p) * dyi;
-        T fx_kappa = fk[0];
         ou = (u00 + dt * (nu00 * (um0 - (T)2 * u00 + up0) * dxi2 + nu00 * (u0m - (T)2 * u00 + u0p) * dyi2 -
-                          u00 * dudx - v_here * dudy + c.gx + div_or_zero<T>(fx_kappa * (T)2, rho00 + rhom0)));
+                          u00 * dudx - v_here * dudy + c.gx + fxf[q]));
       }
       {
         T u_here = (T)0.25 * (u0m + u00 + upm + up0);
         T dvdx = upwind_diff<T>(u_here > 0, v00, vm0, vp0) * dxi;
         T dvdy = upwind_diff<T>(v00 > 0, v00, v0m, v0p) * dyi;
-        T fy_kappa = fk[1];
         ov = (v00 + dt * (nu00 * (vm0 - (T)2 * v00 + vp0) * dxi2 + nu00 * (v0m - (T)2 * v00 + v0p) * dyi2 -
-                          u_here * dvdx - v00 * dvdy + c.gy + div_or_zero<T>(fy_kappa * (T)2, rho00 + rho0m)));
+                          u_here * dvdx - v00 * dvdy + c.gy + fyf[q]));
       }
       const int j = j0 + q;
       us2[q] = (okP && i >= 2 && dom[q]) ? ou : (T)0;           // u* exists on i in [2, nx]
