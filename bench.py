@@ -258,7 +258,7 @@ def main():
     # (1) the north-star kernel: k_jacobi, one sweep per launch, 3 array passes, HBM-bound.  Timed
     #     live with one HIP event pair on the stream the kernels are launched on, around
     #     --jacobi-sweeps-timed back-to-back launches (vof_time_jacobi).  Agrees with rocprofv3.
-    # (2) what the step actually runs: k_jacobi_tb, `tb` sweeps fused per launch (VALU-bound).  Its
+    # (2) what the step actually runs: k_jacobi_tb, `tb` sweeps fused per launch.  Its
     #     duration depends on the clock state: sustained back-to-back launches (event pair, same
     #     call) run ~20 % slower than the two launches interleaved in a real step, so the in-step
     #     cost is also derived from wall-clock step times with and without the pressure sweeps.
@@ -273,7 +273,7 @@ def main():
     violations = eng.get_counter("courant_violations")
     achieved_1 = sweep_bytes / (ms_sweep_1 * 1e-3) / 1e9
     traffic = load_pmc_traffic(nx, ny, a.dtype) if not dist_path else {}
-    fused = {"kernel": "k_jacobi_tb", "sweeps_per_launch": tb, "bound": "valu",
+    fused = {"kernel": "k_jacobi_tb", "sweeps_per_launch": tb, "bound": "hbm (actual traffic: lead-in rows + tile overlap)",
              "us_per_launch_back_to_back": 1e3 * ms_sweep_tb * tb, "us_per_sweep_back_to_back": 1e3 * ms_sweep_tb,
              "hbm_traffic_bytes_per_launch": traffic.get("tb")}
     if not dist_path and a.jacobi_iters > 0 and a.jacobi_iters % tb == 0:
