@@ -55,9 +55,9 @@ def parse():
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="N > 1: halo exchange by the library's own RCCL communicator (no torch in the process) "
                          "or by torch.distributed P2P")
-    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2],
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3],
                     help="N > 1: 0 = one exchange after the step, 1 = each field as soon as it is final, "
-                         "2 = 1 + F's edge bands first (vof_step_exchange)")
+                         "2 = 1 + F's edge bands first, 3 = p, u, v together after the first sweep (vof_step_exchange)")
     return ap.parse_args()
 
 

@@ -165,7 +165,7 @@ struct vof2d_ctx {
   hipStream_t cstream = nullptr; // RCCL's kernels run here, next to the compute stream
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr};  // one per exchange of a step (graph capture forks)
-  hipGraphExec_t gxchg[2][3] = {};   // whole step + exchanges, [istep parity][overlap mode]
+  hipGraphExec_t gxchg[2][4] = {};   // whole step + exchanges, [istep parity][overlap mode]
   int xchg_graph = 1;                // 0 after a failed capture (or VOF2D_XCHG_GRAPH=0): eager launches
   int64_t xchg_steps = 0;            // steps run by vof_step_exchange (the first one is always eager)
   int64_t xchg_graph_steps = 0;      // ... of which replayed from a captured graph
@@ -669,7 +669,7 @@ void comm_teardown(vof2d_ctx* h) {
 // everything enqueued on the compute stream so far; the compute stream does not wait (comm_join).
 void destroy_xchg_graphs(vof2d_ctx* h) {
   for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 3; ++b)
+    for (int b = 0; b < 4; ++b)
       if (h->gxchg[a][b]) { (void)hipGraphExecDestroy(h->gxchg[a][b]); h->gxchg[a][b] = nullptr; }
 }
 int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1) {
@@ -857,7 +857,7 @@ int vof_update_uv(vof2d_handle h) {
 static void sweep_swapped(vof2d_handle h) {
   bool any = h->gexec[0] || h->gexec[1];
   for (int k = 0; k < 9; ++k) any = any || h->gphase[k];
-  for (int k = 0; k < 6; ++k) any = any || h->gxchg[k / 3][k % 3];
+  for (int k = 0; k < 8; ++k) any = any || h->gxchg[k / 4][k % 4];
   if (!any) return;
   (void)hipStreamSynchronize(h->stream);
   destroy_graphs(h);
@@ -1336,14 +1336,15 @@ namespace {
 // One step with its exchanges on (compute stream, communication stream).  mode 0: one exchange of
 // all four fields after the step; 1: each field leaves as soon as it is final (p after phase 0,
 // u, v after phase 1, F after phase 2); 2: like 1, and F's edge bands are produced first so that F
-// travels under the rest of the second sweep.  Enqueued eagerly or under stream capture.
+// travels under the rest of the second sweep; 3: p, u, v together after phase 1, F after phase 2
+// (one fork less).  Enqueued eagerly or under stream capture.
 template <typename T>
 int enqueue_step_exchange(vof2d_ctx* h, int mode) {
   int rc;
   enqueue_phase<T>(h, 0, h->istep);
-  if (mode && (rc = comm_post(h, VOF_XCHG_P, false, 0))) return rc;                 // p is final
+  if ((mode == 1 || mode == 2) && (rc = comm_post(h, VOF_XCHG_P, false, 0))) return rc;   // p is final
   enqueue_phase<T>(h, 1, h->istep);
-  if (mode && (rc = comm_post(h, VOF_XCHG_U | VOF_XCHG_V, false, 1))) return rc;   // u, v are final
+  if (mode && (rc = comm_post(h, mode == 3 ? (VOF_XCHG_P | VOF_XCHG_U | VOF_XCHG_V) : (VOF_XCHG_U | VOF_XCHG_V), false, 1))) return rc;  // u, v are final
   if (mode == 2) {
     enqueue_phase<T>(h, VOF_PHASE_TRANSPORT_EDGES, h->istep);
     if ((rc = comm_post(h, VOF_XCHG_F, /*f_in_twin=*/true, 2))) return rc;
@@ -1357,7 +1358,7 @@ int enqueue_step_exchange(vof2d_ctx* h, int mode) {
 }  // namespace
 extern "C" {
 int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
-  if (!h || nsteps < 0 || overlap < 0 || overlap > 2) return VOF_EINVAL;
+  if (!h || nsteps < 0 || overlap < 0 || overlap > 3) return VOF_EINVAL;
   if (!h->comm) return fail(h, VOF_ESTATE, "vof_comm_init has not been called");
   if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1406,9 +1407,9 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
     }
     h->istep -= 1;  // vof_step_phase(0) advances it
     if ((rc = vof_step_phase(h, 0))) return rc;
-    if (overlap && (rc = comm_post(h, VOF_XCHG_P))) return rc;
+    if ((overlap == 1 || overlap == 2) && (rc = comm_post(h, VOF_XCHG_P))) return rc;
     if ((rc = vof_step_phase(h, 1))) return rc;
-    if (overlap && (rc = comm_post(h, VOF_XCHG_U | VOF_XCHG_V))) return rc;
+    if (overlap && (rc = comm_post(h, overlap == 3 ? (VOF_XCHG_P | VOF_XCHG_U | VOF_XCHG_V) : (VOF_XCHG_U | VOF_XCHG_V)))) return rc;
     if (overlap == 2) {
       if ((rc = vof_step_phase(h, VOF_PHASE_TRANSPORT_EDGES))) return rc;
       if ((rc = comm_post(h, VOF_XCHG_F, /*f_in_twin=*/true))) return rc;

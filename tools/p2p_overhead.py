@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--n", type=int, default=8); ap.add_argument("--nx", type=int, default=8192)
     ap.add_argument("--ny", type=int, default=8192); ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--dt", type=float, default=1e-6)
-    ap.add_argument("--modes", default="compute,native-overlap,native-edges,native-after")
+    ap.add_argument("--modes", default="compute,native-overlap,native-two,native-after")
     ap.add_argument("--rounds", type=int, default=2)
     a = ap.parse_args()
     modes = a.modes.split(",")
@@ -68,6 +68,8 @@ def main():
             e.step_exchange(n, 1)
         elif mode == "native-edges":
             e.step_exchange(n, 2)
+        elif mode == "native-two":
+            e.step_exchange(n, 3)
         elif mode == "native-after":
             e.step_exchange(n, 0)
         else:
