@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
         const T num = b[q] - ae * e.c[q] - aw * w[q] - an[q] * right_of(cur, q) - as_[q] * left_of(cur, q);
         if (i == 1 || i == nx) {  // wave-uniform: the wall rows have their own ap
           const T ap = (T)-1.0 * (ae + aw + an[q] + as_[q]);
-          out[q] = num / ap;
+          out[q] = div_by_const<T>(num, ap, (T)1.0 / ap);   // (the hardware a / b double-rounds subnormal ties)
         } else {
           out[q] = div_by_const<T>(num, apI[q], yI[q]);
         }
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
 #pragma unroll
         for (int q = 0; q < V; ++q) {
           const T ap = (T)-1.0 * (ae + aw + an[q] + as_[q]);
-          T o = num[q] / ap;
+          T o = div_by_const<T>(num[q], ap, (T)1.0 / ap);     // (the hardware a / b double-rounds subnormal ties)
           if (SQ && ((j0 + q) < 1 || (j0 + q) > ny)) o = (T)0;  // same zero the interior rows produce
           carry[q] = o;
         }
