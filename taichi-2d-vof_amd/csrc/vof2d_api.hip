@@ -150,6 +150,7 @@ struct vof2d_ctx {
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
   hipGraphExec_t gphase[9] = {};  // phase 0, then phases 1..4 x istep parity (slot 2 * phase - 1 + parity)
   int next_phase = 0;
+  bool f_ghosts_dirty = true;  // F's ghost cells may not satisfy set_BC (after set_init_F / from_numpy / a single verb)
   void* vis = nullptr;      // scratch for the display fields (vof_get_vis_field / vof_interp_velocity)
   size_t vis_bytes = 0;
   // built-in in-situ profiler (vof_profile_steps): every launch carries a start/stop event pair
@@ -510,10 +511,17 @@ void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
 // the same field.  vof_step on one handle is the three phases back to back; with merge_bc the
 // u, v boundary condition moves behind the second sweep and shares F's launch (full domains only:
 // a strip driver wants u, v complete before it ships them).
+// lean: no boundary launch inside the phases -- the caller applies set_bc<u,v,F,p> once, after the
+// second sweep (and after the halo exchange of a strip).  Valid on a step that starts with F's
+// ghost cells already consistent (every step but the first after set_init_F / from_numpy / a
+// single verb): p's ghosts only ever feed values the wall conditions override (u[1] = 0, v[:,1] =
+// 0) or zero stencil coefficients, and the first sweep itself stores the wall-face zeros of u, v
+// the second sweep reads.
 template <typename T>
-void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false) {
+void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false, bool lean = false) {
   const bool y_first = (istep % 2 == 0);    // :526, :312-318
   const bool corr = h->fuse_correct != 0;
+  if (lean && !(corr && h->fuse_momentum)) lean = false;
   if (phase == 0) {
     // cal_nu_rho (:513) is folded into its consumers: rho/nu = f(F[i,j]) recomputed per cell
     if (h->fuse_momentum) {
@@ -526,14 +534,14 @@ void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false
       L<T>::template rhs<false>(h);         // :521-522, rhs part (iteration invariant)
     }
     jacobi_n<T>(h, h->d.jacobi_iters, false);  // :521-522
-    L<T>::template set_bc<BC_P | BC_F>(h);  // p part of :525 / :528; F part of :518 (first step)
+    if (!lean) L<T>::template set_bc<BC_P | BC_F>(h);  // p part of :525 / :528; F part of :518 (first step)
   } else if (phase == 1) {
     if (corr) {                             // :524 inside the first sweep of :526
       if (y_first) sweep_y<T, false, true>(h); else sweep_x<T, false, true>(h);
     } else {
       L<T>::template correct<false>(h);     // :524
     }
-    if (!(merge_bc && corr)) L<T>::template set_bc<BC_UV>(h);  // u, v part of :525
+    if (!(merge_bc && corr) && !lean) L<T>::template set_bc<BC_UV>(h);  // u, v part of :525
     if (!corr) { if (y_first) sweep_y<T, false>(h); else sweep_x<T, false>(h); }
   } else {
     // second sweep, :527 fused: phase 2 = all owned rows; 3 = the edge bands only (then F's halo
@@ -542,6 +550,7 @@ void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false
     final_sweep<T>(h, /*along_x=*/y_first, part);
     if (phase == 3) return;                 // the new F stays in the twin buffer until phase 4
     swap_F(h);
+    if (lean) return;                       // the caller's single set_bc<u,v,F,p> follows
     // F part of :528 on the rows this handle produced; a strip's halo rows arrive with the
     // sender's ghost columns (and may be arriving right now)
     if (merge_bc && corr) L<T>::template set_bc<BC_UV | BC_F>(h);
@@ -549,9 +558,11 @@ void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false
   }
 }
 template <typename T>
-void enqueue_step(vof2d_ctx* h, int64_t istep) {
+void enqueue_step(vof2d_ctx* h, int64_t istep, bool lean = false) {
   const bool full = h->g.wall_lo && h->g.wall_hi;
-  for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep, full);
+  lean = lean && h->fuse_correct && h->fuse_momentum;
+  for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep, full, lean);
+  if (lean) L<T>::template set_bc<BC_ALL>(h);   // :518, :525, :528 in one launch
 }
 
 int ensure_ok(vof2d_ctx* h) {
@@ -817,11 +828,13 @@ int vof_set_init_F(vof2d_handle h, int32_t ic) {
   if (!h) return VOF_EINVAL;
   if (ic < 1 || ic > 3) return fail(h, VOF_EINVAL, "ic must be 1, 2 or 3 (2dvof.py:13)");
   DISPATCH_T(h, L<double>::init_F(h, ic), L<float>::init_F(h, ic));
+  h->f_ghosts_dirty = true;
   return ensure_ok(h);
 }
 int vof_set_BC(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   DISPATCH_T(h, (L<double>::set_bc<BC_ALL | BC_RHO>(h)), (L<float>::set_bc<BC_ALL | BC_RHO>(h)));
+  h->f_ghosts_dirty = false;
   return ensure_ok(h);
 }
 int vof_cal_nu_rho(vof2d_handle h) {
@@ -865,12 +878,14 @@ static void sweep_swapped(vof2d_handle h) {
 int vof_fct_x_sweep(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   DISPATCH_T(h, (sweep_x<double, false, false>(h)), (sweep_x<float, false, false>(h)));
+  h->f_ghosts_dirty = true;
   sweep_swapped(h);
   return ensure_ok(h);
 }
 int vof_fct_y_sweep(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   DISPATCH_T(h, (sweep_y<double, false, false>(h)), (sweep_y<float, false, false>(h)));
+  h->f_ghosts_dirty = true;
   sweep_swapped(h);
   return ensure_ok(h);
 }
@@ -887,6 +902,7 @@ int vof_solve_VOF_rudman(vof2d_handle h, int64_t istep) {
 int vof_post_process_f(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   DISPATCH_T(h, L<double>::post(h), L<float>::post(h));
+  h->f_ghosts_dirty = true;
   return ensure_ok(h);
 }
 
@@ -898,12 +914,16 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
   for (int64_t s = 0; s < nsteps; ++s) {
     h->istep += 1;
     const int par = (int)(h->istep & 1);
-    if (use_graph) {
+    // A step that starts with consistent F ghosts runs the lean schedule (one boundary launch, at
+    // the end) from a captured graph; the first step after set_init_F / from_numpy / a single verb
+    // runs the schedule with the reference's intermediate set_BC calls, eagerly.
+    const bool lean = !h->f_ghosts_dirty;
+    if (use_graph && lean) {
       if (!h->gexec[par]) {
         // capture one step of this parity; both sweeps swap F twice so pointers are stable
         hipGraph_t graph = nullptr;
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        DISPATCH_T(h, enqueue_step<double>(h, h->istep), enqueue_step<float>(h, h->istep));
+        DISPATCH_T(h, enqueue_step<double>(h, h->istep, true), enqueue_step<float>(h, h->istep, true));
         HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
         hipError_t e = hipGraphInstantiate(&h->gexec[par], graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
@@ -914,10 +934,11 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       }
       HIPCHK(h, hipGraphLaunch(h->gexec[par], h->stream));
     } else {
-      DISPATCH_T(h, enqueue_step<double>(h, h->istep), enqueue_step<float>(h, h->istep));
+      DISPATCH_T(h, enqueue_step<double>(h, h->istep, lean), enqueue_step<float>(h, h->istep, lean));
       int rc = ensure_ok(h);
       if (rc) return rc;
     }
+    h->f_ghosts_dirty = false;
   }
   return VOF_OK;
 }
@@ -929,6 +950,7 @@ int vof_step_phase(vof2d_handle h, int32_t phase) {
   if (!ok) return fail(h, VOF_ESTATE, "vof_step_phase must be called in the order 0, 1, 2 or 0, 1, 3, 4");
   if (phase == 0) h->istep += 1;
   h->next_phase = (phase == 2 || phase == 4) ? 0 : phase + 1;
+  if (phase == 2 || phase == 4) h->f_ghosts_dirty = false;   // the phases carry every set_BC of the step
   const bool use_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
   if (!use_graph) {
     DISPATCH_T(h, enqueue_phase<double>(h, phase, h->istep), enqueue_phase<float>(h, phase, h->istep));
@@ -1015,6 +1037,7 @@ int vof_set_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, const
   if (id < 0) return fail(h, VOF_EINVAL, "unknown field name");
   int rc = copy_rows_host(h, id, g0, g1, const_cast<void*>(src), nbytes, false);
   if (rc == VOF_OK && id == fF) rc = copy_rows_host(h, fF2, g0, g1, const_cast<void*>(src), nbytes, false);
+  if (id == fF || id == fF2) h->f_ghosts_dirty = true;
   return rc;
 }
 int vof_get_field(vof2d_handle h, const char* name, void* dst, size_t nbytes) {
@@ -1205,7 +1228,9 @@ int vof_profile_steps(vof2d_handle h, int64_t nsteps) {
     int batch = 0;
     while (done + batch < nsteps && h->timed + per_step <= vof2d_ctx::kMaxTimed) {
       h->istep += 1;
-      DISPATCH_T(h, enqueue_step<double>(h, h->istep), enqueue_step<float>(h, h->istep));
+      const bool lean = !h->f_ghosts_dirty;
+      DISPATCH_T(h, enqueue_step<double>(h, h->istep, lean), enqueue_step<float>(h, h->istep, lean));
+      h->f_ghosts_dirty = false;
       ++batch;
     }
     const int launches = h->timed;
@@ -1341,19 +1366,25 @@ namespace {
 template <typename T>
 int enqueue_step_exchange(vof2d_ctx* h, int mode) {
   int rc;
-  enqueue_phase<T>(h, 0, h->istep);
+  // lean phases (no boundary launch inside): the rows travel with whatever ghost columns they
+  // have, and one set_bc<u,v,F,p> over all stored rows -- owned and received alike -- follows the
+  // join.  Only reached on steps that start with consistent F ghosts (vof_step_exchange).
+  const bool lean = h->fuse_correct && h->fuse_momentum;
+  enqueue_phase<T>(h, 0, h->istep, false, lean);
   if ((mode == 1 || mode == 2) && (rc = comm_post(h, VOF_XCHG_P, false, 0))) return rc;   // p is final
-  enqueue_phase<T>(h, 1, h->istep);
+  enqueue_phase<T>(h, 1, h->istep, false, lean);
   if (mode && (rc = comm_post(h, mode == 3 ? (VOF_XCHG_P | VOF_XCHG_U | VOF_XCHG_V) : (VOF_XCHG_U | VOF_XCHG_V), false, 1))) return rc;  // u, v are final
   if (mode == 2) {
-    enqueue_phase<T>(h, VOF_PHASE_TRANSPORT_EDGES, h->istep);
+    enqueue_phase<T>(h, VOF_PHASE_TRANSPORT_EDGES, h->istep, false, lean);
     if ((rc = comm_post(h, VOF_XCHG_F, /*f_in_twin=*/true, 2))) return rc;
-    enqueue_phase<T>(h, VOF_PHASE_TRANSPORT_REST, h->istep);
+    enqueue_phase<T>(h, VOF_PHASE_TRANSPORT_REST, h->istep, false, lean);
   } else {
-    enqueue_phase<T>(h, 2, h->istep);
+    enqueue_phase<T>(h, 2, h->istep, false, lean);
     if ((rc = comm_post(h, mode ? VOF_XCHG_F : (VOF_XCHG_F | VOF_XCHG_U | VOF_XCHG_V | VOF_XCHG_P), false, 2))) return rc;
   }
-  return comm_join(h);                          // halos complete before the next step
+  if ((rc = comm_join(h))) return rc;           // halos complete before the next step
+  if (lean) L<T>::template set_bc<BC_ALL>(h);
+  return VOF_OK;
 }
 }  // namespace
 extern "C" {
@@ -1372,7 +1403,7 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
     // compute stream, the send/recv groups forked onto the communication stream, the join -- is
     // one hipGraph per (sweep order, mode): one launch per step instead of four graph launches
     // and three RCCL group launches (~100 us of host time each).
-    if (want_graph && h->xchg_graph && h->xchg_steps > 0) {
+    if (want_graph && h->xchg_graph && h->xchg_steps > 0 && !h->f_ghosts_dirty) {
       if (!h->gxchg[par][overlap]) {
         void* keep[NFIELDS];
         memcpy(keep, h->fld, sizeof(keep));
