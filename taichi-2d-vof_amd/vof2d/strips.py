@@ -121,8 +121,8 @@ class StripSolver:
                 uid = comm_unique_id(self.api)
             except VofError as e:
                 err = e
-        uid = self.comm.broadcast_bytes(uid)
-        if uid is not None:
+        uid = self.comm.broadcast_bytes(uid if uid is not None else b"")   # empty: rank 0 has no RCCL
+        if uid:
             try:
                 self.eng.comm_init(uid, self.rank, self.world)
                 ok = 1
