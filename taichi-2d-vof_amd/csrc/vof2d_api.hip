@@ -251,9 +251,8 @@ int chunk_rows_fit(const vof2d_ctx* h, int ntiles, long capacity, int rmin, int 
             capacity, R_out, ((rows + R_out - 1) / R_out) * ntiles);
   return R_out;
 }
-// cells-per-wave rule for the streaming kernels: ~4096 waves, chunk length a power of two
-// (measured on k_jacobi at 4096^2: 8/16/32/64 rows 78 us, 24/40/48/96 rows 85-96 us -- the row
-// offsets of concurrently streaming waves then spread evenly over the HBM channels)
+// cells-per-wave rule (~4096 waves, chunk length a power of two), used by the x sweep, whose 6
+// lead-in rows per chunk want long chunks (16 rows at 4096^2: 143 us; 8 rows 157 us, 4 rows 200 us)
 int chunk_rows(const vof2d_ctx* h, int ntiles, int rmin, int rmax) {
   const long rows = h->g.ihi - h->g.ilo + 1;
   long R = rows * ntiles / 4096;
@@ -263,9 +262,16 @@ int chunk_rows(const vof2d_ctx* h, int ntiles, int rmin, int rmax) {
   while (P * 2 <= R) P *= 2;
   return (int)(P < rmin ? rmin : P);
 }
+// The streaming kernels with at most one halo row per side (single-sweep Jacobi, y sweep, the
+// per-verb kernels): very short chunks.  With the nontemporal hints on their single-use streams the
+// halo rows of vertically adjacent chunks -- consecutive blocks, resident at the same time -- are
+// L2 hits, and many short-lived waves balance better than few long ones: k_jacobi at 4096^2 fp64
+// 64 us with 2-row chunks (1 row 72 us, 4 rows 65 us, 8 rows 69 us, 32 rows 73.5 us); y sweep 112 us
+// with 1 row, 116 us with 2, 136 us with 16.
 int pick_rows(const vof2d_ctx* h, int ntiles) {
+  (void)ntiles;
   if (h->rows_override > 0) return h->rows_override;
-  return chunk_rows(h, ntiles, 2, 32);
+  return 2;
 }
 inline unsigned blocks_rows(int rows, int ntiles, int R) {
   const long waves = (long)((rows + R - 1) / R) * ntiles;
@@ -407,8 +413,7 @@ struct L {
   template <bool POST, bool CORR>
   static void fct_y(vof2d_ctx* h, int first = 0, int last = 0) {
     if (first == 0 && last == 0) { first = h->g.ilo; last = h->g.ihi; }
-    int R = pick_rows(h, h->nty);
-    if (h->rows_override <= 0 && R > 16) R = 16;
+    const int R = h->rows_override > 0 ? h->rows_override : 1;   // rows are independent in this sweep
     launch(h, kFctY, k_fct_y<T, V, POST, CORR>, dim3(blocks_rows(last - first + 1, h->nty, R)), 0, h->g, C(h),
            (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fV), F_<T>(h, fF2), R, h->nty, (const T*)F_<T>(h, fUS),
            (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
