@@ -358,7 +358,11 @@ struct L {
   static void momentum(vof2d_ctx* h) {
     constexpr int Wt = 64 * V, Ht = ((2 + V - 1) / V) * V, ST = Wt - 2 * Ht;
     const int ntt = (h->g.ny + ST - 1) / ST;
-    const int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, resident_waves(h, k_momentum<T, V>), 4, 64);
+    // one residency round while that keeps the chunks short (strips, small grids); on large grids
+    // several rounds of 14-row chunks beat one round of long ones (4096^2: 184 vs 195 us, 8192^2:
+    // 665 vs 758 us) -- the halo rows of adjacent, simultaneously resident chunks are L2 hits
+    int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, resident_waves(h, k_momentum<T, V>), 4, 64);
+    if (h->mom_rows <= 0 && R > 32) R = 14;
     launch(h, kMomentum, k_momentum<T, V>, dim3(blocks_for(h, ntt, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
            (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt);
   }
