@@ -388,7 +388,7 @@ struct L {
     const int Ht = ((TS - 1 + (sq ? 1 : 0) + V - 1) / V) * V, ST = Wt - 2 * Ht;  // must match the kernel
     const int ntt = (h->g.ny + ST - 1) / ST;
     const long cap = sq ? resident_waves(h, k_jacobi_tb<T, V, TS, true>) : resident_waves(h, k_jacobi_tb<T, V, TS, false>);
-    const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 64);
+    const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
     if (sq)
       launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
              (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
