@@ -55,6 +55,11 @@ def parse():
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="N > 1: halo exchange by the library's own RCCL communicator (no torch in the process) "
                          "or by torch.distributed P2P")
+    ap.add_argument("--attempt-timeout", type=float, default=0.0,
+                    help="N > 1: seconds one attempt (native, then torch) may take before the supervising process "
+                         "kills it and tries the next carrier (default 150 + 0.01 per step)")
+    ap.add_argument("--no-supervisor", action="store_true", help="N > 1: run in this process, no watchdog / fallback")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3],
                     help="N > 1: 0 = one exchange after the step, 1 = each field as soon as it is final, "
                          "2 = 1 + F's edge bands first, 3 = p, u, v together after the first sweep (vof_step_exchange)")
@@ -159,6 +164,51 @@ class _StdoutToStderr:
         return False
 
 
+def supervise(a, rank):
+    """N > 1: run the measurement in a child process per attempt.  This process never touches the
+    GPU; it only watches the clock.  If the in-library RCCL path (send/recv groups captured into the
+    step graph) should hang or die on a machine it has not been tried on, every rank's supervisor
+    times out alike, kills its child and starts the torch.distributed carrier instead, so the run
+    still produces its line.  The workers of one attempt find each other through the launcher's pid
+    (VOF2D_RDZV_TAG) and the attempt number."""
+    import signal
+    carriers = ["native", "torch"] if a.exchange == "native" else ["torch"]
+    limit = a.attempt_timeout if a.attempt_timeout > 0 else 150.0 + 0.01 * (a.steps + a.warmup)
+    argv = [x for x in sys.argv[1:] if x not in ("--child",)]
+    # drop a user-given --exchange (the attempt decides), keep everything else
+    cleaned, skip = [], False
+    for x in argv:
+        if skip:
+            skip = False
+            continue
+        if x == "--exchange":
+            skip = True
+            continue
+        if x.startswith("--exchange="):
+            continue
+        cleaned.append(x)
+    for attempt, carrier in enumerate(carriers):
+        env = dict(os.environ, VOF2D_RDZV_TAG="%d_%d" % (os.getppid(), attempt))
+        cmd = [sys.executable, os.path.abspath(__file__)] + cleaned + ["--child", "--exchange", carrier]
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)     # exactly the group this process started
+            except ProcessLookupError:
+                pass
+            p.wait()
+            print("[bench] rank %d: %s attempt exceeded %.0f s, killed" % (rank, carrier, limit), file=sys.stderr)
+            continue
+        if p.returncode == 0:
+            sys.stdout.write(out.decode())
+            sys.stdout.flush()
+            return 0
+        print("[bench] rank %d: %s attempt exited with code %d" % (rank, carrier, p.returncode), file=sys.stderr)
+    return 1
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +219,10 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if (world > 1 or a.force_dist) and not a.child and not a.no_supervisor:
+        raise SystemExit(supervise(a, rank))
+    if os.environ.get("VOF2D_BENCH_TEST_HANG") == a.exchange and a.child:   # self-test of the watchdog
+        time.sleep(1e6)
     nx = a.nx or (4096 if world == 1 else 8192)
     ny = a.ny or nx
     esz = 8 if a.dtype == "f64" else 4

@@ -50,7 +50,9 @@ class EnvComm:
         self.world = int(env.get("WORLD_SIZE", 1)) if world is None else world
         self.local_rank = int(env.get("LOCAL_RANK", self.rank)) if local_rank is None else local_rank
         # one directory per launch: the launcher's pid (the workers' common parent) and its port
-        tag = "%s_%s_%s" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+        # (VOF2D_RDZV_TAG: set by a supervising parent process, whose own parent the workers share)
+        tag = "%s_%s_%s" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"),
+                            env.get("VOF2D_RDZV_TAG") or os.getppid())
         self.dir = rdzv_dir or os.path.join(env.get("VOF2D_RDZV_DIR", "/tmp"), "vof2d_rdzv_" + tag)
         os.makedirs(self.dir, exist_ok=True)
         self.timeout = timeout
