@@ -57,7 +57,7 @@ def parse():
                          "or by torch.distributed P2P")
     ap.add_argument("--attempt-timeout", type=float, default=0.0,
                     help="N > 1: seconds one attempt (native, then torch) may take before the supervising process "
-                         "kills it and tries the next carrier (default 150 + 0.01 per step)")
+                         "kills it and tries the next carrier (default 300 + 0.01 per step; three times that for torch)")
     ap.add_argument("--no-supervisor", action="store_true", help="N > 1: run in this process, no watchdog / fallback")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3],
@@ -173,7 +173,9 @@ def supervise(a, rank):
     (VOF2D_RDZV_TAG) and the attempt number."""
     import signal
     carriers = ["native", "torch"] if a.exchange == "native" else ["torch"]
-    limit = a.attempt_timeout if a.attempt_timeout > 0 else 150.0 + 0.01 * (a.steps + a.warmup)
+    # generous: on a fresh box the first load of the HIP runtime and of RCCL (a 570 MB library) can
+    # take a minute; the limit only matters if the attempt hangs
+    limit = a.attempt_timeout if a.attempt_timeout > 0 else 300.0 + 0.01 * (a.steps + a.warmup)
     argv = [x for x in sys.argv[1:] if x not in ("--child",)]
     # drop a user-given --exchange (the attempt decides), keep everything else
     cleaned, skip = [], False
@@ -192,7 +194,7 @@ def supervise(a, rank):
         cmd = [sys.executable, os.path.abspath(__file__)] + cleaned + ["--child", "--exchange", carrier]
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
         try:
-            out, _ = p.communicate(timeout=limit)
+            out, _ = p.communicate(timeout=limit if carrier == "native" else 3 * limit)
         except subprocess.TimeoutExpired:
             try:
                 os.killpg(p.pid, signal.SIGKILL)     # exactly the group this process started
