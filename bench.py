@@ -189,10 +189,28 @@ def supervise(a, rank):
         if x.startswith("--exchange="):
             continue
         cleaned.append(x)
+    def die_with_parent():
+        # the child must not outlive this process (a launcher that tears its workers down would
+        # otherwise leave GPU-holding orphans): PR_SET_PDEATHSIG = 1
+        ctypes.CDLL(None).prctl(1, int(signal.SIGKILL), 0, 0, 0)
+
+    current = {"p": None}
+
+    def on_term(signum, frame):
+        p = current["p"]
+        if p is not None and p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        sys.exit(128 + signum)
+    signal.signal(signal.SIGTERM, on_term)
+    signal.signal(signal.SIGINT, on_term)
     for attempt, carrier in enumerate(carriers):
         env = dict(os.environ, VOF2D_RDZV_TAG="%d_%d" % (os.getppid(), attempt))
         cmd = [sys.executable, os.path.abspath(__file__)] + cleaned + ["--child", "--exchange", carrier]
-        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, preexec_fn=die_with_parent)
+        current["p"] = p
         try:
             out, _ = p.communicate(timeout=limit if carrier == "native" else 3 * limit)
         except subprocess.TimeoutExpired:
