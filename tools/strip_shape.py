@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--n", type=int, default=8); ap.add_argument("--rank", type=int, default=3)
     ap.add_argument("--nx", type=int, default=8192); ap.add_argument("--ny", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=30); ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--skip", type=int, default=10, help="steps before the measurement")
     ap.add_argument("--dt", type=float, default=0.0, help="default: 4e-6 up to 4096^2, 1e-6 above (stability, DESIGN.md 4)")
     ap.add_argument("--sweep", default="", help="param=v1,v2,...: wall us/step per value, 3 interleaved rounds")
     a = ap.parse_args()
@@ -28,7 +29,7 @@ def main():
     dt = a.dt if a.dt > 0 else (4e-6 if max(a.nx, a.ny) <= 4096 else 1e-6)
     e = Engine(api, make_desc(api, a.nx, a.ny, a.dtype, "f32", rows=rows, own=own, device=0, dt=dt))
     e.set_init_F(1)
-    e.step(10); e.sync()
+    e.step(a.skip); e.sync()
     if a.sweep:
         name, vals = a.sweep.split("=")
         vals = [float(v) for v in vals.split(",")]
