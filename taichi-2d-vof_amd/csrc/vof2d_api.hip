@@ -144,7 +144,7 @@ struct vof2d_ctx {
   int tb_rows = 0;      // rows per wave chunk of the fused kernel (0 = heuristic)
   int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
   int tb_general = 0;   // force the general (dx != dy) fused Jacobi kernel
-  int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = 64)
+  int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = heuristic, at most 16)
   int fuse_momentum = 1;
   int fuse_correct = 1; // vof_step on a full domain: update_uv inside the first FCT sweep
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
