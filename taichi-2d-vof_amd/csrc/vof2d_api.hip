@@ -758,7 +758,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
     return VOF_EINVAL;  // a grid/time-step constant with an all-ones significand (see divisors_ok)
   }
   h->esz = d->dtype == VOF_F64 ? 8 : 4;
-  h->V = 16 / (int)h->esz;
+  h->V = d->dtype == VOF_F64 ? VecWidth<double>::V : VecWidth<float>::V;
   const int W = 64 * h->V;
   Geom& g = h->g;
   g.nx = d->nx; g.ny = d->ny; g.row_lo = d->row_lo; g.row_hi = d->row_hi;

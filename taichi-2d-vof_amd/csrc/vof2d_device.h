@@ -40,7 +40,11 @@ struct Consts {
   T ic1_x2, ic1_y2, ic_r, ic_cx, ic2_cy, ic3_cy, ic3_pool;
 };
 
-template <typename T> struct VecWidth { static constexpr int V = 16 / sizeof(T); };
+// Elements per lane and row: 2 for both precisions, i.e. a wave tile is 128 columns.  (16 bytes per
+// lane -- 4 floats, 256-column tiles -- halves the number of tiles, and with it the chunk length a
+// residency round allows, so the lead-in rows of every chunk weigh twice as much: fp32 at 4096^2
+// 601 us/step with V = 4, 443 us/step with V = 2; 2048^2 249 -> 174 us.)
+template <typename T> struct VecWidth { static constexpr int V = 2; };
 
 template <typename T, int V>
 struct alignas(sizeof(T) * V) Pack {
