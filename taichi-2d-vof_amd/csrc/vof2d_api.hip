@@ -144,6 +144,7 @@ struct vof2d_ctx {
   int tb_rows = 0;      // rows per wave chunk of the fused kernel (0 = heuristic)
   int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
   int tb_general = 0;   // force the general (dx != dy) fused Jacobi kernel
+  int tb_narrow = 1;    // allow the one-column-per-lane fused Jacobi kernel on thin strips
   int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = heuristic, at most 16)
   int fuse_momentum = 1;
   int fuse_correct = 1; // vof_step on a full domain: update_uv inside the first FCT sweep
@@ -379,22 +380,45 @@ struct L {
     launch(h, kJacobi, k_jacobi<T, V, 2, RESID>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h),
            (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, h->d_courant + 1);
   }
-  // TS sweeps src -> dst in one launch
+  // TS sweeps src -> dst in one launch, with VV columns per lane
+  template <int TS, int VV>
+  static int jacobi_tb_plan(vof2d_ctx* h, bool sq, int& ntt) {
+    constexpr int Wt = 64 * VV;
+    const int Ht = ((TS - 1 + (sq ? 1 : 0) + VV - 1) / VV) * VV, ST = Wt - 2 * Ht;  // must match the kernel
+    ntt = (h->g.ny + ST - 1) / ST;
+    const long cap = sq ? resident_waves(h, k_jacobi_tb<T, VV, TS, true>) : resident_waves(h, k_jacobi_tb<T, VV, TS, false>);
+    return h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
+  }
+  template <int TS, int VV>
+  static void jacobi_tb_launch(vof2d_ctx* h, const Consts<T>& cc, bool sq, int src, int dst, int R, int ntt) {
+    if (sq)
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
+    else
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
+  }
   template <int TS>
   static void jacobi_tb(vof2d_ctx* h, int src, int dst) {
     const Consts<T> cc = C(h);
     const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;  // square cells: the product-carrying pipeline
-    constexpr int Wt = 64 * V;
-    const int Ht = ((TS - 1 + (sq ? 1 : 0) + V - 1) / V) * V, ST = Wt - 2 * Ht;  // must match the kernel
-    const int ntt = (h->g.ny + ST - 1) / ST;
-    const long cap = sq ? resident_waves(h, k_jacobi_tb<T, V, TS, true>) : resident_waves(h, k_jacobi_tb<T, V, TS, false>);
-    const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
-    if (sq)
-      launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
-    else
-      launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
+    int ntt = 0;
+    const int R = jacobi_tb_plan<TS, V>(h, sq, ntt);
+    // Thin, wide strips (what strong scaling produces: 1056 x 8192 per GPU at 8 GPUs): the variant
+    // with one column per lane needs 71 VGPRs, so 7 waves/SIMD are resident instead of 3, and that
+    // is worth more there than the wider tile: 70 vs 77 us per launch.  (Planning it for fewer
+    // resident waves and longer chunks -- fewer lead-in rows -- is slower: 75 / 87 / 100 us for
+    // 5 / 4 / 3 waves per SIMD.)  On full grids two columns per lane win (4096^2: 89 vs 103 us,
+    // 2048^2: 30 vs 35 us).  Square cells, five sweeps, fp64 only.
+    if constexpr (sizeof(T) == 8 && TS == 5 && V == 2) {
+      if (sq && R < 32 && ntt >= 48 && h->tb_rows <= 0 && h->tb_narrow != 0) {
+        int ntt1 = 0;
+        const int R1 = jacobi_tb_plan<TS, 1>(h, sq, ntt1);
+        jacobi_tb_launch<TS, 1>(h, cc, sq, src, dst, R1, ntt1);
+        return;
+      }
+    }
+    jacobi_tb_launch<TS, V>(h, cc, sq, src, dst, R, ntt);
   }
   template <bool STORED>
   static void correct(vof2d_ctx* h) {
@@ -782,6 +806,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   if ((ev = getenv("VOF2D_TB_ROWS"))) h->tb_rows = atoi(ev);
   if ((ev = getenv("VOF2D_FCTX_ROWS"))) h->fctx_rows = atoi(ev);
   if ((ev = getenv("VOF2D_TB_GENERAL"))) h->tb_general = atoi(ev);
+  if ((ev = getenv("VOF2D_TB_NARROW"))) h->tb_narrow = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_CORRECT"))) h->fuse_correct = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_MOMENTUM"))) h->fuse_momentum = atoi(ev);
   if ((ev = getenv("VOF2D_MOM_ROWS"))) h->mom_rows = atoi(ev);
