@@ -8,7 +8,7 @@
 // wave's 16-byte-per-lane accesses are aligned and never straddle rows.
 //
 // Work decomposition: one 64-lane wave owns a tile of 64*V contiguous columns
-// (V = 16 bytes / sizeof(T): 2 doubles or 4 floats per lane) and marches along
+// (V = 2 elements per lane, VecWidth below) and marches along
 // i over a chunk of rows, keeping the i-1 / i / i+1 rows in registers so each
 // element is fetched from HBM once.  j-1 / j+V neighbours come from L1 hits or
 // cross-lane shuffles.  Waves never synchronise with each other (no LDS, no
