@@ -124,6 +124,19 @@ __device__ __forceinline__ double lane_dn(double x) {
 }
 __device__ __forceinline__ float lane_up(float x) { return __int_as_float(dpp_up(__float_as_int(x))); }
 __device__ __forceinline__ float lane_dn(float x) { return __int_as_float(dpp_dn(__float_as_int(x))); }
+// Zero-filling forms (bound_ctrl): lane 0 / lane 63 receive 0 instead of keeping their own value,
+// which lets the move read its source register directly (no copy first).  For kernels whose tile
+// edge columns are recomputed by the neighbouring tile anyway.
+__device__ __forceinline__ int dpp_up_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_dn_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ double lane_up_z(double x) {
+  return __hiloint2double(dpp_up_z(__double2hiint(x)), dpp_up_z(__double2loint(x)));
+}
+__device__ __forceinline__ double lane_dn_z(double x) {
+  return __hiloint2double(dpp_dn_z(__double2hiint(x)), dpp_dn_z(__double2loint(x)));
+}
+__device__ __forceinline__ float lane_up_z(float x) { return __int_as_float(dpp_up_z(__float_as_int(x))); }
+__device__ __forceinline__ float lane_dn_z(float x) { return __int_as_float(dpp_dn_z(__float_as_int(x))); }
 
 // ------------------------------------------------------------------ exact division by a lane constant
 // a / b for a denominator that is constant per lane (ap of the Jacobi stencil).  With
@@ -1058,8 +1071,8 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
         sl = sideL[kC];
         sr = sideR[kC];
       } else {
-        sl = lane_up(ring[s - 1][kC][V - 1]);
-        sr = lane_dn(ring[s - 1][kC][0]);
+        sl = lane_up_z(ring[s - 1][kC][V - 1]);   // (tile edge lanes: columns in the overlap, recomputed next door)
+        sr = lane_dn_z(ring[s - 1][kC][0]);
       }
       if (s > 1) {
         if (SQ) {  // publish the previous stage's row i+1 as products (zero coefficient outside [1, nx])
