@@ -146,6 +146,7 @@ struct vof2d_ctx {
   int tb_general = 0;   // force the general (dx != dy) fused Jacobi kernel
   int tb_narrow = 1;    // allow the one-column-per-lane fused Jacobi kernel on thin strips
   int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = heuristic, at most 16)
+  int fctx_corr_rows = 0;  // ... of its update_uv-carrying form (0 = same rule)
   int fuse_momentum = 1;
   int fuse_correct = 1; // vof_step on a full domain: update_uv inside the first FCT sweep
   hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
@@ -433,7 +434,8 @@ struct L {
   template <bool POST, bool CORR>
   static void fct_x(vof2d_ctx* h, int first = 0, int last = 0) {
     if (first == 0 && last == 0) { first = h->g.ilo; last = h->g.ihi; }
-    const int R = h->fctx_rows > 0 ? h->fctx_rows : chunk_rows(h, h->g.ntj, 4, 16);
+    const int forced = CORR && h->fctx_corr_rows > 0 ? h->fctx_corr_rows : h->fctx_rows;
+    const int R = forced > 0 ? forced : chunk_rows(h, h->g.ntj, 4, 16);
     launch(h, kFctX, k_fct_x<T, V, POST, CORR>, dim3(blocks_rows(last - first + 1, h->g.ntj, R)), 0, h->g, C(h),
            (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fU), F_<T>(h, fF2), R, (const T*)F_<T>(h, fUS),
            (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
@@ -1181,8 +1183,12 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
     return VOF_OK;
   }
   if (!strcmp(name, "jacobi_tb") || !strcmp(name, "jacobi_tb_rows") || !strcmp(name, "momentum_rows") ||
-      !strcmp(name, "fuse_momentum") || !strcmp(name, "fuse_correct")) {  // tuning knobs
+      !strcmp(name, "fuse_momentum") || !strcmp(name, "fuse_correct") || !strcmp(name, "fctx_rows") ||
+      !strcmp(name, "fctx_corr_rows") || !strcmp(name, "jacobi_tb_narrow")) {  // tuning knobs
     if (!strcmp(name, "jacobi_tb")) h->tb = (int)value;
+    else if (!strcmp(name, "fctx_rows")) h->fctx_rows = (int)value;
+    else if (!strcmp(name, "fctx_corr_rows")) h->fctx_corr_rows = (int)value;
+    else if (!strcmp(name, "jacobi_tb_narrow")) h->tb_narrow = (int)value;
     else if (!strcmp(name, "jacobi_tb_rows")) h->tb_rows = (int)value;
     else if (!strcmp(name, "momentum_rows")) h->mom_rows = (int)value;
     else if (!strcmp(name, "fuse_correct")) h->fuse_correct = (int)value;
@@ -1300,6 +1306,32 @@ int vof_reset_profile(vof2d_handle h) {
   for (int k = 0; k < NKERNELS; ++k) { h->prof_sum_ms[k] = 0.0; h->prof_cnt[k] = 0; }
   return VOF_OK;
 }
+#ifdef VOF_WAVE_TIMES
+// Diagnostic build only (make wavetimes; tools/wave_balance.py).  Arms the per-wave start/end
+// stamps for kernel `kid` (KernelId) with room for `cap` waves, or reads them back (out != NULL).
+extern "C" int vof_debug_wave_times(vof2d_handle h, int32_t kid, uint64_t* out, uint32_t cap) {
+  static unsigned long long* buf = nullptr;
+  static unsigned int bufcap = 0;
+  if (!h) return VOF_EINVAL;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (out) {
+    if (!buf || cap > bufcap) return VOF_EINVAL;
+    HIPCHK(h, hipMemcpy(out, buf, (size_t)cap * 16, hipMemcpyDeviceToHost));
+    return VOF_OK;
+  }
+  if (cap > bufcap) {
+    if (buf) (void)hipFree(buf);
+    HIPCHK(h, hipMalloc(&buf, (size_t)cap * 16));
+    bufcap = cap;
+  }
+  HIPCHK(h, hipMemset(buf, 0, (size_t)bufcap * 16));
+  int k = kid;
+  HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(vof::vof_wave_times), &buf, sizeof(buf)));
+  HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(vof::vof_wave_kid), &k, sizeof(k)));
+  HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(vof::vof_wave_cap), &bufcap, sizeof(bufcap)));
+  return VOF_OK;
+}
+#endif
 int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep) {
   if (!h || !ms_per_sweep) return VOF_EINVAL;
   if (n < 2 || (n & 1)) return fail(h, VOF_EINVAL, "n must be even and >= 2");

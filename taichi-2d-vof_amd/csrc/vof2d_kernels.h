@@ -13,6 +13,33 @@
 namespace vof {
 
 // ------------------------------------------------------------------ helpers
+// Diagnostic build only (-DVOF_WAVE_TIMES, tools/wave_balance.py): every wave of the selected kernel
+// records when it started and ended (s_memrealtime, 100 MHz), which shows how evenly a launch's
+// waves finish.  The product build compiles WaveTimer to nothing.
+#ifdef VOF_WAVE_TIMES
+__device__ unsigned long long* vof_wave_times = nullptr;  // [2 * wave] = start, [2 * wave + 1] = end
+__device__ int vof_wave_kid = -1;
+__device__ unsigned int vof_wave_cap = 0;
+struct WaveTimer {
+  unsigned long long t0;
+  unsigned int wave;
+  bool on;
+  __device__ __forceinline__ WaveTimer(int kid) {
+    on = vof_wave_times != nullptr && vof_wave_kid == kid;
+    wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    t0 = on ? wall_clock64() : 0ull;
+  }
+  __device__ __forceinline__ ~WaveTimer() {
+    if (on && (threadIdx.x & 63) == 0 && wave < vof_wave_cap) {
+      vof_wave_times[2 * wave] = t0;
+      vof_wave_times[2 * wave + 1] = wall_clock64();
+    }
+  }
+};
+#else
+struct WaveTimer { __device__ __forceinline__ WaveTimer(int) {} };
+#endif
+enum : int { WT_MOMENTUM = 0, WT_JACOBI_TB = 3, WT_FCT_X = 5, WT_FCT_Y = 6, WT_JACOBI = 2 };  // = KernelId of the runtime
 template <typename T, int V>
 struct Row {  // one row of a wave tile as seen by a lane: j0-1 | j0..j0+V-1 | j0+V
   T l;
@@ -681,6 +708,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
                                                    int R, int ntt) {
   constexpr int W = 64 * V;
   constexpr int H = ((2 + V - 1) / V) * V;
+  WaveTimer wt_(WT_MOMENTUM);
   constexpr int STRIDE = W - 2 * H;
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -893,6 +921,7 @@ template <typename T, int V, int D, bool RESID>
 __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __restrict__ p,
                                                  const T* __restrict__ rhs, T* __restrict__ pn, int R,
                                                  unsigned long long* __restrict__ resid_bits) {
+  WaveTimer wt_(WT_JACOBI);
   int j0, ra, rb;
   if (!wave_tile<V>(g, g.ilo, g.ihi, R, j0, ra, rb)) return;
   const int nx = g.nx, ny = g.ny;
@@ -989,6 +1018,7 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
   // outside [1, nx] publish 0 * value, and cells in columns outside [1, ny] carry the value 0
   // (their reciprocal yI is 0, so div_by_const returns 0), whose product is the same exact zero.
   static_assert(TS >= 2 && TS <= 5, "rhs ring holds 6 rows");
+  WaveTimer wt_(WT_JACOBI_TB);
   constexpr int W = 64 * V;
   // invalid columns per tile side after TS sweeps: TS-1 from the cross-lane exchange of sweeps
   // 2..TS, plus 1 when the first sweep also takes its j-neighbours from adjacent lanes (SQ)
@@ -1284,6 +1314,7 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
                                                 const T* __restrict__ p, T* __restrict__ Uo, T* __restrict__ Vo,
                                                 unsigned long long* __restrict__ courant, int rfirst, int rlast) {
   // rows [rfirst, rlast] (within [ilo, ihi]) are produced; the sweep's domain stays [ilo, ihi]
+  WaveTimer wt_(WT_FCT_X);
   int j0, ra, rb;
   if (!wave_tile<V>(g, rfirst, rlast, R, j0, ra, rb)) return;
   const int ilo = g.ilo, ihi = g.ihi;
@@ -1457,6 +1488,7 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
                                                 const T* __restrict__ p, T* __restrict__ Uo, T* __restrict__ Vo,
                                                 unsigned long long* __restrict__ courant, int rfirst, int rlast) {
   constexpr int W = 64 * V, STRIDE = W - 8;
+  WaveTimer wt_(WT_FCT_Y);
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR: rows are wave-uniform
   const int lane = threadIdx.x & 63;
   const int tj = wave % nty, ch = wave / nty;

@@ -18,12 +18,18 @@ def main():
     ap.add_argument("--skip", type=int, default=10, help="steps before the measurement")
     ap.add_argument("--dt", type=float, default=0.0, help="default: 4e-6 up to 4096^2, 1e-6 above (stability, DESIGN.md 4)")
     ap.add_argument("--sweep", default="", help="param=v1,v2,...: wall us/step per value, 3 interleaved rounds")
+    ap.add_argument("--kernel", default="", help="with --sweep: report this kernel's profiled us per launch instead of the wall time per step")
+    ap.add_argument("--lib", default="", help="A/B runs: another build of the library (e.g. csrc/build/variants/libvof2d_base.so)")
     a = ap.parse_args()
     from vof2d._lib import hip_api
     from vof2d import _abi
     from vof2d.engine import Engine, make_desc
     from vof2d.strips import partition, stored_rows
-    api = hip_api()
+    if a.lib:
+        import ctypes
+        api = _abi.bind(ctypes.CDLL(os.path.join(ROOT, a.lib)), "vof_")
+    else:
+        api = hip_api()
     own = partition(a.nx, a.n)[a.rank]
     rows = stored_rows(a.nx, own, _abi.halo_rows(10))
     dt = a.dt if a.dt > 0 else (4e-6 if max(a.nx, a.ny) <= 4096 else 1e-6)
@@ -38,10 +44,14 @@ def main():
             for v in vals:
                 e.set_param(name, v)
                 e.step(6); e.sync()
+                if a.kernel:
+                    prof = e.profile_steps(8)
+                    res[v].append(prof[a.kernel][0] if a.kernel in prof else float("nan"))
+                    continue
                 t0 = time.perf_counter(); e.step(a.steps); e.sync()
                 res[v].append(1e6 * (time.perf_counter() - t0) / a.steps)
         for v in vals:
-            print("%s=%-6g  %s us/step" % (name, v, "  ".join("%.1f" % x for x in res[v])))
+            print("%s=%-6g  %s us/%s" % (name, v, "  ".join("%.1f" % x for x in res[v]), a.kernel or "step"))
         return
     t0 = time.perf_counter(); e.step(a.steps); e.sync(); dt = (time.perf_counter() - t0) / a.steps
     prof = e.profile_steps(10)
