@@ -25,9 +25,11 @@ sys.path.insert(0, os.path.join(ROOT, "taichi-2d-vof_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
 # distinct arrays read or written per cell per step by the fused schedule (DESIGN.md "schedule"):
-# k_momentum 6 (F,u,v -> u*,v*,rhs) + 2 x k_jacobi_tb 3 + first FCT sweep with update_uv 7
-# (F,u*,v*,p -> F',u,v) + second FCT sweep 3; strips run the same schedule
-ARRAYS_PER_STEP = 22
+# k_momentum 6 (F,u,v -> u*,v*,rhs) + 2 x k_jacobi_tb 3 + k_transport 7 (F,u*,v*,p -> F'',u,v: update_uv
+# and both FCT sweeps in one pass) = 19 on a full domain; a strip runs the two sweeps as two kernels
+# (first sweep with update_uv 7 + second sweep 3, u / v leave for the neighbours in between) = 22
+ARRAYS_PER_STEP_FULL = 19
+ARRAYS_PER_STEP_STRIP = 22
 
 
 def parse():
@@ -390,6 +392,11 @@ def main():
     prof = eng.profile_steps(14) if not dist_path else {}
     kernels_us = {k: round(v[0], 2) for k, v in prof.items()}
 
+    try:
+        one_kernel_transport = bool(eng.get_param("fuse_transport")) and exchange == "none"
+    except Exception:
+        one_kernel_transport = False
+    ARRAYS_PER_STEP = ARRAYS_PER_STEP_FULL if one_kernel_transport else ARRAYS_PER_STEP_STRIP
     if rank == 0:
         out = {
             "metric": "cell-updates/sec (whole node), %dx%d %s dam-break" % (nx, ny, "fp64" if esz == 8 else "fp32"),

@@ -149,7 +149,10 @@ struct vof2d_ctx {
   int fctx_corr_rows = 0;  // ... of its update_uv-carrying form (0 = same rule)
   int fuse_momentum = 1;
   int fuse_correct = 1; // vof_step on a full domain: update_uv inside the first FCT sweep
-  hipGraphExec_t gexec[2] = {nullptr, nullptr};  // whole step, [istep parity]
+  int fuse_transport = 1;  // ... and both FCT sweeps in one kernel (k_transport), full domains only
+  void* f_home = nullptr;  // the buffer fld[fF] pointed to at creation (orientation of the F / twin pair)
+  int phase_graph_ori = 0; // orientation the gphase / gxchg graphs were captured in
+  hipGraphExec_t gexec[2][2] = {};  // whole step, [istep parity][F in its home buffer ? 0 : 1]
   hipGraphExec_t gphase[9] = {};  // phase 0, then phases 1..4 x istep parity (slot 2 * phase - 1 + parity)
   int next_phase = 0;
   bool f_ghosts_dirty = true;  // F's ghost cells may not satisfy set_BC (after set_init_F / from_numpy / a single verb)
@@ -288,10 +291,10 @@ inline unsigned blocks_for(const vof2d_ctx* h, int ntiles, int R) {
 
 // ------------------------------------------------------------------ launches
 enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
-                kRhs, kOther, NKERNELS };
+                kRhs, kOther, kTransport, NKERNELS };
 const char* const kKernelNames[NKERNELS] = {"k_momentum", "k_set_bc", "k_jacobi", "k_jacobi_tb", "k_correct",
                                             "k_fct_x", "k_fct_y", "k_normals", "k_kappa", "k_predictor", "k_rhs",
-                                            "other"};
+                                            "other", "k_transport"};
 
 // One place through which every kernel is launched.  In profiling mode the dispatch carries its
 // own start/stop events (hipExtLaunchKernelGGL: the begin/end timestamps of the dispatch itself,
@@ -448,6 +451,14 @@ struct L {
            (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fV), F_<T>(h, fF2), R, h->nty, (const T*)F_<T>(h, fUS),
            (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
   }
+  // update_uv + both sweeps + post_process_f in one pass (k_transport); reads fld[fF], writes fld[fF2]
+  template <bool YFIRST>
+  static void transport(vof2d_ctx* h) {
+    const int R = h->fctx_corr_rows > 0 ? h->fctx_corr_rows : chunk_rows(h, h->nty, 4, 16);
+    launch(h, kTransport, k_transport<T, V, YFIRST>, dim3(blocks_for(h, h->nty, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fF), F_<T>(h, fF2), R, h->nty, (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS),
+           (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant);
+  }
 };
 
 void swap_F(vof2d_ctx* h) {
@@ -596,6 +607,15 @@ template <typename T>
 void enqueue_step(vof2d_ctx* h, int64_t istep, bool lean = false) {
   const bool full = h->g.wall_lo && h->g.wall_hi;
   lean = lean && h->fuse_correct && h->fuse_momentum;
+  if (lean && full && h->fuse_transport) {
+    // :524 + :526-527 as ONE kernel: the first sweep's F never goes to memory.  One swap of the
+    // F / twin pair per step (the two-kernel form swaps twice).
+    enqueue_phase<T>(h, 0, istep, full, lean);
+    if (istep % 2 == 0) L<T>::template transport<true>(h); else L<T>::template transport<false>(h);
+    swap_F(h);
+    L<T>::template set_bc<BC_ALL>(h);
+    return;
+  }
   for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep, full, lean);
   if (lean) L<T>::template set_bc<BC_ALL>(h);   // :518, :525, :528 in one launch
 }
@@ -631,7 +651,8 @@ void destroy_xchg_graphs(vof2d_ctx* h);
 void destroy_graphs(vof2d_ctx* h) {
   destroy_xchg_graphs(h);
   for (int k = 0; k < 2; ++k)
-    if (h->gexec[k]) { (void)hipGraphExecDestroy(h->gexec[k]); h->gexec[k] = nullptr; }
+    for (int o = 0; o < 2; ++o)
+      if (h->gexec[k][o]) { (void)hipGraphExecDestroy(h->gexec[k][o]); h->gexec[k][o] = nullptr; }
   for (int k = 0; k < 9; ++k)
     if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }
 }
@@ -810,6 +831,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   if ((ev = getenv("VOF2D_TB_GENERAL"))) h->tb_general = atoi(ev);
   if ((ev = getenv("VOF2D_TB_NARROW"))) h->tb_narrow = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_CORRECT"))) h->fuse_correct = atoi(ev);
+  if ((ev = getenv("VOF2D_FUSE_TRANSPORT"))) h->fuse_transport = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_MOMENTUM"))) h->fuse_momentum = atoi(ev);
   if ((ev = getenv("VOF2D_MOM_ROWS"))) h->mom_rows = atoi(ev);
 
@@ -829,6 +851,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
     if (hipMalloc(reinterpret_cast<void**>(&h->arena), bytes) != hipSuccess) { rc = VOF_ENOMEM; break; }
     if (hipMemsetAsync(h->arena, 0, bytes, h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     for (int k = 0; k < NFIELDS; ++k) h->fld[k] = h->arena + (size_t)k * h->field_elems * h->esz;
+    h->f_home = h->fld[fF];
     if (hipMalloc(reinterpret_cast<void**>(&h->d_courant), 2 * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
     if (hipMemsetAsync(h->d_courant, 0, 2 * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = VOF_EHIP; break; }
@@ -904,7 +927,7 @@ int vof_update_uv(vof2d_handle h) {
 // A single sweep swaps F with its twin, so field pointers baked into captured step graphs go
 // stale: drop the graphs (they are re-captured on the next vof_step / vof_step_phase).
 static void sweep_swapped(vof2d_handle h) {
-  bool any = h->gexec[0] || h->gexec[1];
+  bool any = h->gexec[0][0] || h->gexec[0][1] || h->gexec[1][0] || h->gexec[1][1];
   for (int k = 0; k < 9; ++k) any = any || h->gphase[k];
   for (int k = 0; k < 8; ++k) any = any || h->gxchg[k / 4][k % 4];
   if (!any) return;
@@ -955,20 +978,25 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
     // runs the schedule with the reference's intermediate set_BC calls, eagerly.
     const bool lean = !h->f_ghosts_dirty;
     if (use_graph && lean) {
-      if (!h->gexec[par]) {
-        // capture one step of this parity; both sweeps swap F twice so pointers are stable
+      // graphs bake the field pointers in: one per (parity, which buffer of the F / twin pair holds
+      // F).  The two-kernel transport swaps the pair twice per step, the fused one once.
+      const int ori = h->fld[fF] == h->f_home ? 0 : 1;
+      const bool one_swap = h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->fuse_correct && h->fuse_momentum;
+      if (!h->gexec[par][ori]) {
         hipGraph_t graph = nullptr;
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         DISPATCH_T(h, enqueue_step<double>(h, h->istep, true), enqueue_step<float>(h, h->istep, true));
         HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
-        hipError_t e = hipGraphInstantiate(&h->gexec[par], graph, nullptr, nullptr, 0);
+        hipError_t e = hipGraphInstantiate(&h->gexec[par][ori], graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) {
           snprintf(h->err, sizeof(h->err), "hipGraphInstantiate: %s", hipGetErrorString(e));
           return VOF_EHIP;
         }
+        if (one_swap) swap_F(h);   // capturing ran enqueue_step, which swapped the host's view: undo, redo below
       }
-      HIPCHK(h, hipGraphLaunch(h->gexec[par], h->stream));
+      HIPCHK(h, hipGraphLaunch(h->gexec[par][ori], h->stream));
+      if (one_swap) swap_F(h);     // keep the host's view in step with what the replayed kernels did
     } else {
       DISPATCH_T(h, enqueue_step<double>(h, h->istep, lean), enqueue_step<float>(h, h->istep, lean));
       int rc = ensure_ok(h);
@@ -978,13 +1006,36 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
   }
   return VOF_OK;
 }
+// The phase and exchange graphs bake the F / twin pointers in and assume the pair returns to the
+// same orientation after every step (two swaps).  vof_step's fused transport swaps once per step,
+// so a handle that mixes the two entry points may arrive here with the pair the other way round:
+// drop those graphs then (they are re-captured on use).
+static int match_phase_graph_orientation(vof2d_handle h) {
+  const int ori = h->fld[fF] == h->f_home ? 0 : 1;
+  if (ori == h->phase_graph_ori) return VOF_OK;
+  bool any = false;
+  for (int k = 0; k < 9; ++k) any = any || h->gphase[k];
+  for (int k = 0; k < 8; ++k) any = any || h->gxchg[k / 4][k % 4];
+  if (any) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    destroy_xchg_graphs(h);
+    for (int k = 0; k < 9; ++k)
+      if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }
+  }
+  h->phase_graph_ori = ori;
+  return VOF_OK;
+}
 int vof_step_phase(vof2d_handle h, int32_t phase) {
   if (!h) return VOF_EINVAL;
   if (phase < 0 || phase > 4) return fail(h, VOF_EINVAL, "phase must be 0 ... 4");
   // order: 0, 1, then 2 or (3, 4)
   const bool ok = phase == h->next_phase || (phase == VOF_PHASE_TRANSPORT_EDGES && h->next_phase == 2);
   if (!ok) return fail(h, VOF_ESTATE, "vof_step_phase must be called in the order 0, 1, 2 or 0, 1, 3, 4");
-  if (phase == 0) h->istep += 1;
+  if (phase == 0) {
+    int rc = match_phase_graph_orientation(h);
+    if (rc) return rc;
+    h->istep += 1;
+  }
   h->next_phase = (phase == 2 || phase == 4) ? 0 : phase + 1;
   if (phase == 2 || phase == 4) h->f_ghosts_dirty = false;   // the phases carry every set_BC of the step
   const bool use_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
@@ -1183,7 +1234,8 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
     return VOF_OK;
   }
   if (!strcmp(name, "jacobi_tb") || !strcmp(name, "jacobi_tb_rows") || !strcmp(name, "momentum_rows") ||
-      !strcmp(name, "fuse_momentum") || !strcmp(name, "fuse_correct") || !strcmp(name, "fctx_rows") ||
+      !strcmp(name, "fuse_momentum") || !strcmp(name, "fuse_correct") || !strcmp(name, "fuse_transport") ||
+      !strcmp(name, "fctx_rows") ||
       !strcmp(name, "fctx_corr_rows") || !strcmp(name, "jacobi_tb_narrow")) {  // tuning knobs
     if (!strcmp(name, "jacobi_tb")) h->tb = (int)value;
     else if (!strcmp(name, "fctx_rows")) h->fctx_rows = (int)value;
@@ -1192,6 +1244,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
     else if (!strcmp(name, "jacobi_tb_rows")) h->tb_rows = (int)value;
     else if (!strcmp(name, "momentum_rows")) h->mom_rows = (int)value;
     else if (!strcmp(name, "fuse_correct")) h->fuse_correct = (int)value;
+    else if (!strcmp(name, "fuse_transport")) h->fuse_transport = (int)value;
     else h->fuse_momentum = (int)value;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     destroy_graphs(h);
@@ -1217,6 +1270,10 @@ int vof_get_param(vof2d_handle h, const char* name, double* value) {
   if (!strcmp(name, "pitch")) { *value = (double)h->g.pitch; return VOF_OK; }
   if (!strcmp(name, "rows_per_wave")) { *value = (double)pick_rows(h, h->g.ntj); return VOF_OK; }
   if (!strcmp(name, "jacobi_tb")) { *value = (double)h->tb; return VOF_OK; }
+  if (!strcmp(name, "fuse_transport")) {  // 1 if vof_step runs both FCT sweeps as one kernel on this handle
+    *value = (h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->fuse_correct && h->fuse_momentum) ? 1.0 : 0.0;
+    return VOF_OK;
+  }
   return fail(h, VOF_EINVAL, "unknown parameter");
 }
 int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
@@ -1460,6 +1517,10 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
   if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
   HIPCHK(h, hipSetDevice(h->device));
   const bool want_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
+  {
+    int rc0 = match_phase_graph_orientation(h);
+    if (rc0) return rc0;
+  }
   for (int64_t s = 0; s < nsteps; ++s) {
     h->istep += 1;
     const int par = (int)(h->istep & 1);

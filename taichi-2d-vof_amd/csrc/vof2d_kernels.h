@@ -1303,6 +1303,105 @@ __device__ __forceinline__ T corrected_velocity(const Consts<T>& c, T star, T rh
   return star - c.dt / r * (pc - pm) * di;
 }
 
+// fct_y_sweep for one row segment: a wave's 64*V consecutive cells, valid for the inner columns
+// [c0+4, c0+W-5] (the j+-3 dependency is resolved across lanes; tiles overlap by 8 columns)
+template <typename T, int V, bool POST>
+__device__ __forceinline__ void fct_y_row(const Consts<T>& c, int j0, int ny, const T (&Fz)[V], const T (&vz)[V],
+                                          T (&out)[V]) {
+  const T Fl = lane_up(Fz[V - 1]);
+  T L[V], a[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) fct_face<T>(vz[q], c.dt, q == 0 ? Fl : Fz[q - 1], Fz[q], L[q], a[q]);
+  const T Ln = lane_dn(L[0]), an_ = lane_dn(a[0]), vn = lane_dn(vz[0]);
+  T td[V], dv[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const int j = j0 + q;
+    dv[q] = c.dxdy - c.dtdx * ((q == V - 1 ? vn : vz[q + 1]) - vz[q]);
+    td[q] = (j >= 1 && j <= ny) ? fct_ftd<T>(c, Fz[q], L[q], q == V - 1 ? Ln : L[q + 1], dv[q]) : (T)0;
+  }
+  const T tl = lane_up(td[V - 1]), tr = lane_dn(td[0]);
+  T rp[V], rm[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const int j = j0 + q;
+    rp[q] = rm[q] = (T)0;
+    if (j >= 1 && j <= ny)
+      fct_ratios<T>(c, td[q], q == 0 ? tl : td[q - 1], q == V - 1 ? tr : td[q + 1], a[q],
+                    q == V - 1 ? an_ : a[q + 1], rp[q], rm[q]);
+  }
+  const T rpl = lane_up(rp[V - 1]), rml = lane_up(rm[V - 1]);
+  T cy[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const int j = j0 + q;  // face j between cells j-1 and j; written for j in [2, ny+1]
+    cy[q] = (j >= 2 && j <= ny + 1)
+                ? fct_climit<T>(a[q], q == 0 ? rpl : rp[q - 1], q == 0 ? rml : rm[q - 1], rp[q], rm[q])
+                : (T)0;
+  }
+  const T cn = lane_dn(cy[0]);
+#pragma unroll
+  for (int q = 0; q < V; ++q)
+    out[q] = fct_final<T, POST>(c, td[q], a[q], cy[q], q == V - 1 ? an_ : a[q + 1], q == V - 1 ? cn : cy[q + 1],
+                                dv[q]);
+}
+
+// fct_x_sweep as a pipeline along i (see k_fct_x): push row r of F and of the face velocity u,
+// receive row r-3 of the swept F.  State indices are relative to the newest row.
+template <typename T, int V>
+struct FctXPipe {
+  T F1[V], u1[V], L1[V], a1[V], a2[V], a3[V], t2[V], t3[V], d2[V], d3[V], rp3[V], rm3[V], c3[V];
+  int zrows;
+  __device__ __forceinline__ void init(const T (&Fm)[V]) {  // Fm = F[row before the first pushed row]
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      F1[q] = Fm[q];
+      u1[q] = L1[q] = a1[q] = a2[q] = a3[q] = t2[q] = t3[q] = rp3[q] = rm3[q] = c3[q] = (T)0;
+      d2[q] = d3[q] = (T)1;
+    }
+    zrows = 0;
+  }
+  template <bool POST>
+  __device__ __forceinline__ void push(const Consts<T>& c, int r, int ilo, int ihi, const T (&Fr)[V],
+                                       const T (&ur)[V], T (&out)[V]) {
+    bool rz = true;
+#pragma unroll
+    for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
+    zrows = __all(rz) ? zrows + 1 : 0;
+    if (zrows >= 7) {  // the whole dependency window F[r-6..r] of the wave is zero: every output is
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const T dv1 = c.dxdy - c.dtdy * (ur[q] - u1[q]);
+        out[q] = (T)0;
+        F1[q] = Fr[q]; u1[q] = ur[q]; L1[q] = (T)0;
+        a3[q] = a2[q] = a1[q] = (T)0;
+        t3[q] = t2[q] = (T)0;
+        d3[q] = d2[q]; d2[q] = dv1;
+        rp3[q] = rm3[q] = c3[q] = (T)0;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        T Lr, ar;
+        fct_face<T>(ur[q], c.dt, F1[q], Fr[q], Lr, ar);
+        const int i1 = r - 1;
+        T dv1 = c.dxdy - c.dtdy * (ur[q] - u1[q]);
+        T tn = (i1 >= ilo && i1 <= ihi) ? fct_ftd<T>(c, F1[q], L1[q], Lr, dv1) : (T)0;
+        const int i2 = r - 2;
+        T rp2 = (T)0, rm2 = (T)0;
+        if (i2 >= ilo && i2 <= ihi) fct_ratios<T>(c, t2[q], t3[q], tn, a2[q], a1[q], rp2, rm2);
+        T c2 = (i2 > ilo && i2 <= ihi + 1) ? fct_climit<T>(a2[q], rp3[q], rm3[q], rp2, rm2) : (T)0;
+        out[q] = fct_final<T, POST>(c, t3[q], a3[q], c3[q], a2[q], c2, d3[q]);
+        F1[q] = Fr[q]; u1[q] = ur[q]; L1[q] = Lr;
+        a3[q] = a2[q]; a2[q] = a1[q]; a1[q] = ar;
+        t3[q] = t2[q]; t2[q] = tn;
+        d3[q] = d2[q]; d2[q] = dv1;
+        rp3[q] = rp2; rm3[q] = rm2; c3[q] = c2;
+      }
+    }
+  }
+};
+
 // CORR (full-domain handles only): the sweep that runs first also performs update_uv -- it
 // computes u and v from u*, v*, p and F (rho) for the rows it streams, stores them, and feeds its
 // own component straight into the flux pipeline.  `u` is then an output (Uo) and the wall faces
@@ -1318,26 +1417,14 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
   int j0, ra, rb;
   if (!wave_tile<V>(g, rfirst, rlast, R, j0, ra, rb)) return;
   const int ilo = g.ilo, ihi = g.ihi;
-  // state, indexed relative to the newest row r
-  T F1[V];                       // F[r-1]
-  T u1[V];                       // u[r-1]
-  T L1[V];                       // L(r-1)
-  T a1[V], a2[V], a3[V];         // a(r-1), a(r-2), a(r-3)
-  T t2[V], t3[V];                // Ftd[r-2], Ftd[r-3]  (Ftd[r-1] is produced in iteration r)
-  T d2[V], d3[V];                // dv[r-2], dv[r-3]
-  T rp3[V], rm3[V];              // rp/rm[r-3]
-  T c3[V];                       // cx(face r-3)
-#pragma unroll
-  for (int q = 0; q < V; ++q) {
-    u1[q] = L1[q] = a1[q] = a2[q] = a3[q] = t2[q] = t3[q] = rp3[q] = rm3[q] = c3[q] = (T)0;
-    d2[q] = d3[q] = (T)1;
-  }
+  FctXPipe<T, V> pipe;  // face -> Ftd -> rp/rm -> cx -> F' along i
   auto rowptr = [&](const T* base, int r) {
     int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
     return base + at(g, rc, j0);
   };
+  T F1[V];  // F[r-1]: the pipeline's first donor row, and update_uv's i-1 density
   load_c<T, V>(F1, rowptr(F, ra - 3));
-  int zrows = 0;
+  pipe.init(F1);
   T Fnx[V], unx[V];  // rows r of F and u (CORR: u*), prefetched one iteration ahead
   load_c<T, V>(Fnx, rowptr(F, ra - 2));
   load_c<T, V>(unx, rowptr(CORR ? us : u, ra - 2));
@@ -1420,52 +1507,11 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
         rho1[q] = rhor[q];
       }
     }
-    T out[V];
     // Where F is identically 0 (the gas side of the interface) every flux, F~, limiter and the new
-    // F are exact zeros.  zrows counts the consecutive newest rows in which every lane of the wave
-    // loaded only zeros (wave-uniform); once the whole 7-row dependency window F[r-6..r] is zero
-    // the pipeline is bypassed: only dv (which depends on u alone) keeps being tracked.
-    bool rz = true;
-#pragma unroll
-    for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
-    zrows = __all(rz) ? zrows + 1 : 0;
-    if (zrows >= 7) {
-#pragma unroll
-      for (int q = 0; q < V; ++q) {
-        const T dv1 = c.dxdy - c.dtdy * (ur[q] - u1[q]);
-        out[q] = (T)0;
-        F1[q] = Fr[q]; u1[q] = ur[q]; L1[q] = (T)0;
-        a3[q] = a2[q] = a1[q] = (T)0;
-        t3[q] = t2[q] = (T)0;
-        d3[q] = d2[q]; d2[q] = dv1;
-        rp3[q] = rm3[q] = c3[q] = (T)0;
-      }
-    } else {
-#pragma unroll
-    for (int q = 0; q < V; ++q) {
-      // S1: face r
-      T Lr, ar;
-      fct_face<T>(ur[q], c.dt, F1[q], Fr[q], Lr, ar);
-      // S2: Ftd[r-1], dv[r-1]
-      const int i1 = r - 1;
-      T dv1 = c.dxdy - c.dtdy * (ur[q] - u1[q]);
-      T tn = (i1 >= ilo && i1 <= ihi) ? fct_ftd<T>(c, F1[q], L1[q], Lr, dv1) : (T)0;
-      // S3: rp/rm[r-2]
-      const int i2 = r - 2;
-      T rp2 = (T)0, rm2 = (T)0;
-      if (i2 >= ilo && i2 <= ihi) fct_ratios<T>(c, t2[q], t3[q], tn, a2[q], a1[q], rp2, rm2);
-      // S4: cx(face r-2) between cells r-3 and r-2
-      T c2 = (i2 > ilo && i2 <= ihi + 1) ? fct_climit<T>(a2[q], rp3[q], rm3[q], rp2, rm2) : (T)0;
-      // S5: F'[r-3]
-      out[q] = fct_final<T, POST>(c, t3[q], a3[q], c3[q], a2[q], c2, d3[q]);
-      // shift the pipeline
-      F1[q] = Fr[q]; u1[q] = ur[q]; L1[q] = Lr;
-      a3[q] = a2[q]; a2[q] = a1[q]; a1[q] = ar;
-      t3[q] = t2[q]; t2[q] = tn;
-      d3[q] = d2[q]; d2[q] = dv1;
-      rp3[q] = rp2; rm3[q] = rm2; c3[q] = c2;
-    }
-    }
+    // F are exact zeros: the pipeline bypasses itself once the wave's whole 7-row dependency window
+    // is zero (FctXPipe::push).
+    T out[V];
+    pipe.template push<POST>(c, r, ilo, ihi, Fr, ur, out);
     const int io = r - 3;
     if (io >= ra && io <= rb) store_s<T, V>(Fn + at(g, io, j0), out, j0, 1, g.ny);
   }
@@ -1579,43 +1625,8 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
         continue;
       }
     }
-    const T Fl = lane_up(Fz[V - 1]);
-    T L[V], a[V];
-#pragma unroll
-    for (int q = 0; q < V; ++q) fct_face<T>(vz[q], c.dt, q == 0 ? Fl : Fz[q - 1], Fz[q], L[q], a[q]);
-    const T Ln = lane_dn(L[0]), an_ = lane_dn(a[0]), vn = lane_dn(vz[0]);
-    T td[V], dv[V];
-#pragma unroll
-    for (int q = 0; q < V; ++q) {
-      const int j = j0 + q;
-      dv[q] = c.dxdy - c.dtdx * ((q == V - 1 ? vn : vz[q + 1]) - vz[q]);
-      td[q] = (j >= 1 && j <= ny) ? fct_ftd<T>(c, Fz[q], L[q], q == V - 1 ? Ln : L[q + 1], dv[q]) : (T)0;
-    }
-    const T tl = lane_up(td[V - 1]), tr = lane_dn(td[0]);
-    T rp[V], rm[V];
-#pragma unroll
-    for (int q = 0; q < V; ++q) {
-      const int j = j0 + q;
-      rp[q] = rm[q] = (T)0;
-      if (j >= 1 && j <= ny)
-        fct_ratios<T>(c, td[q], q == 0 ? tl : td[q - 1], q == V - 1 ? tr : td[q + 1], a[q],
-                      q == V - 1 ? an_ : a[q + 1], rp[q], rm[q]);
-    }
-    const T rpl = lane_up(rp[V - 1]), rml = lane_up(rm[V - 1]);
-    T cy[V];
-#pragma unroll
-    for (int q = 0; q < V; ++q) {
-      const int j = j0 + q;  // face j between cells j-1 and j; written for j in [2, ny+1]
-      cy[q] = (j >= 2 && j <= ny + 1)
-                  ? fct_climit<T>(a[q], q == 0 ? rpl : rp[q - 1], q == 0 ? rml : rm[q - 1], rp[q], rm[q])
-                  : (T)0;
-    }
-    const T cn = lane_dn(cy[0]);
     T out[V];
-#pragma unroll
-    for (int q = 0; q < V; ++q)
-      out[q] = fct_final<T, POST>(c, td[q], a[q], cy[q], q == V - 1 ? an_ : a[q + 1], q == V - 1 ? cn : cy[q + 1],
-                                  dv[q]);
+    fct_y_row<T, V, POST>(c, j0, ny, Fz, vz, out);
     store_s<T, V>(Fn + o, out, j0, jlo, jhi);
   }
   if (CORR && __any(viol != 0)) {
@@ -1625,5 +1636,169 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
     if ((threadIdx.x & 63) == 0) atomicAdd(courant, (unsigned long long)tot);
   }
 }
+
+// ------------------------------------------------------------------ fused transport
+// update_uv (2dvof.py:269-280) + BOTH FCT sweeps of solve_VOF_rudman (:312-318, :321-448) +
+// post_process_f (:452-455) in one pass over F, u*, v*, p -> F'', u, v: the intermediate F' of the
+// first sweep never goes to memory (7 array passes instead of 10 for the two-kernel form).
+// Possible because the y sweep is row-local: while a wave marches along i for the x sweep's
+// pipeline, the y sweep of a row is a per-row stage in front of that pipeline (YFIRST, even steps:
+// y then x) or behind it (odd steps: x then y).  Same per-cell functions, same operands, same
+// order as k_fct_x / k_fct_y, so F'' is identical.  Full domains only (the strip schedule ships u, v
+// between the two sweeps).
+//
+// The reference applies no set_BC between the sweeps (S6): the second sweep sees F's ghost cells
+// from before the first one.  Here those are simply the input's ghost cells: rows outside
+// [ilo, ihi] enter the x pipeline unswept (YFIRST), and F' in the ghost columns only ever meets the
+// zero wall velocity v[:,1] = v[:,ny+1] = 0 (x first).
+
+template <typename T, int V, bool YFIRST>
+__global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T* __restrict__ F, T* __restrict__ Fn,
+                                                    int R, int nty, const T* __restrict__ us,
+                                                    const T* __restrict__ vs, const T* __restrict__ p,
+                                                    T* __restrict__ Uo, T* __restrict__ Vo,
+                                                    unsigned long long* __restrict__ courant) {
+  constexpr int W = 64 * V, STRIDE = W - 8;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int tj = wave % nty, ch = wave / nty;
+  const int c0 = -3 + tj * STRIDE;
+  const int j0 = c0 + lane * V;
+  const int ilo = g.ilo, ihi = g.ihi, nx = g.nx, ny = g.ny;
+  const int ra = ilo + ch * R;
+  if (ra > ihi) return;  // wave-uniform
+  const int rb = ra + R - 1 < ihi ? ra + R - 1 : ihi;
+  const int jlo = c0 + 4 > 1 ? c0 + 4 : 1;
+  const int jhi = c0 + W - 5 < ny ? c0 + W - 5 : ny;
+  auto rowptr = [&](const T* base, int r) {
+    const int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
+    return base + at(g, rc, j0);
+  };
+  FctXPipe<T, V> pipe;
+  T p1[V], rho1[V];   // p and rho of the previous row (update_uv's i-1 operands)
+  {
+    T f1[V];
+    load_c<T, V>(f1, rowptr(F, ra - 3));
+    load_c<T, V>(p1, rowptr(p, ra - 3));
+#pragma unroll
+    for (int q = 0; q < V; ++q) rho1[q] = rho_of(c, f1[q]);
+    if (YFIRST && ra - 3 >= ilo) {
+      // the pipeline's first donor cell is row ra-3 of the y-swept F: sweep that row here (its
+      // corrected v needs operands of the same row only)
+      T v0[V], fs[V];
+      load_s<T, V>(v0, rowptr(vs, ra - 3));
+      const T rhol = lane_up(rho1[V - 1]), pl = lane_up(p1[V - 1]);
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const int j = j0 + q;
+        const T vn = corrected_velocity<T>(c, v0[q], rho1[q], q == 0 ? rhol : rho1[q - 1], p1[q],
+                                           q == 0 ? pl : p1[q - 1], c.dyi);
+        v0[q] = (j >= 2 && j <= ny) ? vn : (T)0;
+      }
+      fct_y_row<T, V, false>(c, j0, ny, f1, v0, fs);
+      pipe.init(fs);
+    } else {
+      pipe.init(f1);
+    }
+  }
+  T v1[V], v2[V], v3[V];  // x first: corrected v of rows r-1, r-2, r-3 (the y sweep trails the pipeline)
+#pragma unroll
+  for (int q = 0; q < V; ++q) v1[q] = v2[q] = v3[q] = (T)0;
+  T Fnx[V], usnx[V], vsnx[V], pnx[V];  // row r, prefetched one iteration ahead
+  load_c<T, V>(Fnx, rowptr(F, ra - 2));
+  load_s<T, V>(usnx, rowptr(us, ra - 2));
+  load_s<T, V>(vsnx, rowptr(vs, ra - 2));
+  load_c<T, V>(pnx, rowptr(p, ra - 2));
+  unsigned int viol = 0;
+  for (int r = ra - 2; r <= rb + 3; ++r) {
+    T Fr[V], ur[V], vr[V], pr[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      Fr[q] = Fnx[q]; ur[q] = usnx[q]; vr[q] = vsnx[q]; pr[q] = pnx[q];
+    }
+    if (r < rb + 3) {
+      load_c<T, V>(Fnx, rowptr(F, r + 1));
+      load_s<T, V>(usnx, rowptr(us, r + 1));
+      load_s<T, V>(vsnx, rowptr(vs, r + 1));
+      load_c<T, V>(pnx, rowptr(p, r + 1));
+    }
+    {  // update_uv for row r (:269-280): ur / vr hold u*[r] / v*[r]
+      T rhor[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) rhor[q] = rho_of(c, Fr[q]);
+      const T rhol = lane_up(rhor[V - 1]), pl = lane_up(pr[V - 1]);
+      const bool urow = r >= 2 && r <= nx;     // u exists on i in [2, nx]; the walls keep 0
+      const bool own = r >= ra && r <= rb;     // rows this chunk stores (and counts)
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const int j = j0 + q;
+        const T un = corrected_velocity<T>(c, ur[q], rhor[q], rho1[q], pr[q], p1[q], c.dxi);
+        ur[q] = urow ? un : (T)0;
+        const T vn = corrected_velocity<T>(c, vr[q], rhor[q], q == 0 ? rhol : rhor[q - 1], pr[q],
+                                           q == 0 ? pl : pr[q - 1], c.dyi);
+        vr[q] = (j >= 2 && j <= ny) ? vn : (T)0;   // v exists on j in [2, ny]; j = 1, ny+1 keep set_BC's 0
+        if (own && j >= jlo && j <= jhi && r >= g.own_lo && r <= g.own_hi) {
+          if (urow && ur[q] * c.dt > c.cfl_x) viol++;
+          if (j >= 2 && vr[q] * c.dt > c.cfl_y) viol++;
+        }
+        p1[q] = pr[q];
+        rho1[q] = rhor[q];
+      }
+      if (own) {
+        store_s<T, V>(Uo + at(g, r, j0), ur, j0, jlo, jhi);
+        store_s<T, V>(Vo + at(g, r, j0), vr, j0, jlo, jhi == ny ? ny + 1 : jhi);
+        if (r == nx) {
+          T zero[V];
+#pragma unroll
+          for (int q = 0; q < V; ++q) zero[q] = (T)0;
+          store_c<T, V>(Uo + at(g, r + 1, j0), zero, j0, jlo, jhi);
+        }
+      }
+    }
+    T out[V];
+    const int io = r - 3;
+    if (YFIRST) {
+      // y sweep of row r in front of the pipeline; rows outside [ilo, ihi] (the ghost rows) enter
+      // unswept, which is what the twin buffer holds for the x sweep in the two-kernel form
+      T Fp[V];
+      bool rz = true;
+#pragma unroll
+      for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
+      if (r < ilo || r > ihi || __all(rz)) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) Fp[q] = Fr[q];
+      } else {
+        fct_y_row<T, V, false>(c, j0, ny, Fr, vr, Fp);
+      }
+      pipe.template push<true>(c, r, ilo, ihi, Fp, ur, out);
+    } else {
+      T Fp[V];
+      pipe.template push<false>(c, r, ilo, ihi, Fr, ur, Fp);   // F'[r-3]
+      if (io >= ra && io <= rb) {
+        bool rz = true;
+#pragma unroll
+        for (int q = 0; q < V; ++q) rz = rz && Fp[q] == (T)0;
+        if (__all(rz)) {
+#pragma unroll
+          for (int q = 0; q < V; ++q) out[q] = (T)0;
+        } else {
+          fct_y_row<T, V, true>(c, j0, ny, Fp, v3, out);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        v3[q] = v2[q]; v2[q] = v1[q]; v1[q] = vr[q];
+      }
+    }
+    if (io >= ra && io <= rb) store_s<T, V>(Fn + at(g, io, j0), out, j0, jlo, jhi);
+  }
+  if (__any(viol != 0)) {
+    unsigned int tot = viol;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) tot += __shfl_down(tot, sft, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(courant, (unsigned long long)tot);
+  }
+}
+
 
 }  // namespace vof
