@@ -150,12 +150,16 @@ struct vof2d_ctx {
   int fuse_momentum = 1;
   int fuse_correct = 1; // vof_step on a full domain: update_uv inside the first FCT sweep
   int fuse_transport = 1;  // ... and both FCT sweeps in one kernel (k_transport), full domains only
+  int virtual_ghosts = 1;  // ... without the step's set_BC launch (k_momentum forms the ghost cells it reads)
   void* f_home = nullptr;  // the buffer fld[fF] pointed to at creation (orientation of the F / twin pair)
   int phase_graph_ori = 0; // orientation the gphase / gxchg graphs were captured in
   hipGraphExec_t gexec[2][2] = {};  // whole step, [istep parity][F in its home buffer ? 0 : 1]
   hipGraphExec_t gphase[9] = {};  // phase 0, then phases 1..4 x istep parity (slot 2 * phase - 1 + parity)
   int next_phase = 0;
   bool f_ghosts_dirty = true;  // F's ghost cells may not satisfy set_BC (after set_init_F / from_numpy / a single verb)
+  bool uv_ghosts_dirty = false; // u / v were written without a set_BC since (update_uv verb, from_numpy): their ghost cells are not mirror images
+  bool ghosts_virtual = false; // the last fused step skipped its set_BC launch: the ghost cells in memory are stale
+                               // (k_momentum forms the ones it reads; everything else goes through settle_ghosts)
   void* vis = nullptr;      // scratch for the display fields (vof_get_vis_field / vof_interp_velocity)
   size_t vis_bytes = 0;
   // built-in in-situ profiler (vof_profile_steps): every launch carries a start/stop event pair
@@ -360,7 +364,7 @@ struct L {
            (const T*)F_<T>(h, fRHO), (const T*)F_<T>(h, fNU), F_<T>(h, fUS), F_<T>(h, fVS), R);
   }
   // fused normals + kappa + predictor + rhs (vof_step only)
-  static void momentum(vof2d_ctx* h) {
+  static void momentum(vof2d_ctx* h, bool virt = false) {
     constexpr int Wt = 64 * V, Ht = ((2 + V - 1) / V) * V, ST = Wt - 2 * Ht;
     const int ntt = (h->g.ny + ST - 1) / ST;
     // one residency round while that keeps the chunks short (strips, small grids); on large grids
@@ -369,7 +373,8 @@ struct L {
     int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, resident_waves(h, k_momentum<T, V>), 4, 64);
     if (h->mom_rows <= 0 && R > 32) R = 14;
     launch(h, kMomentum, k_momentum<T, V>, dim3(blocks_for(h, ntt, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
-           (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt);
+           (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
+           virt ? 1 : 0);
   }
   template <bool STORED>
   static void rhs(vof2d_ctx* h) {
@@ -604,16 +609,22 @@ void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false
   }
 }
 template <typename T>
-void enqueue_step(vof2d_ctx* h, int64_t istep, bool lean = false) {
+void enqueue_step(vof2d_ctx* h, int64_t istep, bool lean = false, bool virt = false) {
   const bool full = h->g.wall_lo && h->g.wall_hi;
   lean = lean && h->fuse_correct && h->fuse_momentum;
   if (lean && full && h->fuse_transport) {
     // :524 + :526-527 as ONE kernel: the first sweep's F never goes to memory.  One swap of the
     // F / twin pair per step (the two-kernel form swaps twice).
-    enqueue_phase<T>(h, 0, istep, full, lean);
+    // With virtual ghosts the step's one set_BC launch goes as well: after it, the only reader of
+    // ghost cells is the next step's k_momentum (the sweeps meet F's ghosts only at faces whose
+    // wall velocity is zero, update_uv overwrites what p's ghosts would enter, the Jacobi stencil
+    // multiplies them by zero coefficients), and that kernel forms them from the interior cells
+    // itself.  Whoever else looks at the fields goes through settle_ghosts first.
+    L<T>::momentum(h, virt);
+    jacobi_n<T>(h, h->d.jacobi_iters, false);
     if (istep % 2 == 0) L<T>::template transport<true>(h); else L<T>::template transport<false>(h);
     swap_F(h);
-    L<T>::template set_bc<BC_ALL>(h);
+    if (!virt) L<T>::template set_bc<BC_ALL>(h);
     return;
   }
   for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep, full, lean);
@@ -631,6 +642,20 @@ int ensure_ok(vof2d_ctx* h) {
 
 #define DISPATCH_T(h, expr_d, expr_f) \
   do { if ((h)->d.dtype == VOF_F64) { expr_d; } else { expr_f; } } while (0)
+
+// true if the next vof_step runs the fused full-domain schedule (k_momentum, 2 x k_jacobi_tb,
+// k_transport) that leaves the ghost cells virtual
+bool step_leaves_ghosts_virtual(const vof2d_ctx* h) {
+  return h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->fuse_correct && h->fuse_momentum &&
+         h->virtual_ghosts && !h->f_ghosts_dirty && !h->uv_ghosts_dirty;
+}
+// Every entry point that reads or writes fields other than through the fused step calls this
+// first: if the last step skipped its set_BC launch, run it now (u, v, F with its twin, p).
+void settle_ghosts(vof2d_ctx* h) {
+  if (!h->ghosts_virtual) return;
+  DISPATCH_T(h, L<double>::set_bc<BC_ALL>(h), L<float>::set_bc<BC_ALL>(h));
+  h->ghosts_virtual = false;
+}
 
 int copy_rows_host(vof2d_ctx* h, int id, int g0, int g1, void* host, size_t nbytes, bool to_host) {
   if (g0 < h->d.row_lo || g1 > h->d.row_hi || g1 < g0) return fail(h, VOF_EINVAL, "row range not stored by this handle");
@@ -832,6 +857,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   if ((ev = getenv("VOF2D_TB_NARROW"))) h->tb_narrow = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_CORRECT"))) h->fuse_correct = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_TRANSPORT"))) h->fuse_transport = atoi(ev);
+  if ((ev = getenv("VOF2D_VIRTUAL_GHOSTS"))) h->virtual_ghosts = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_MOMENTUM"))) h->fuse_momentum = atoi(ev);
   if ((ev = getenv("VOF2D_MOM_ROWS"))) h->mom_rows = atoi(ev);
 
@@ -886,6 +912,7 @@ int vof_destroy(vof2d_handle h) {
 int vof_set_init_F(vof2d_handle h, int32_t ic) {
   if (!h) return VOF_EINVAL;
   if (ic < 1 || ic > 3) return fail(h, VOF_EINVAL, "ic must be 1, 2 or 3 (2dvof.py:13)");
+  settle_ghosts(h);
   DISPATCH_T(h, L<double>::init_F(h, ic), L<float>::init_F(h, ic));
   h->f_ghosts_dirty = true;
   return ensure_ok(h);
@@ -894,25 +921,31 @@ int vof_set_BC(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   DISPATCH_T(h, (L<double>::set_bc<BC_ALL | BC_RHO>(h)), (L<float>::set_bc<BC_ALL | BC_RHO>(h)));
   h->f_ghosts_dirty = false;
+  h->uv_ghosts_dirty = false;
+  h->ghosts_virtual = false;   // this launch is the one a fused step left out
   return ensure_ok(h);
 }
 int vof_cal_nu_rho(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
+  settle_ghosts(h);
   DISPATCH_T(h, L<double>::nu_rho(h), L<float>::nu_rho(h));
   return ensure_ok(h);
 }
 int vof_get_normal_young(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
+  settle_ghosts(h);
   DISPATCH_T(h, (L<double>::normals(h), L<double>::kappa(h)), (L<float>::normals(h), L<float>::kappa(h)));
   return ensure_ok(h);
 }
 int vof_advect_upwind(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
+  settle_ghosts(h);
   DISPATCH_T(h, L<double>::predictor<true>(h), L<float>::predictor<true>(h));
   return ensure_ok(h);
 }
 int vof_solve_p_jacobi(vof2d_handle h, int32_t n) {
   if (!h) return VOF_EINVAL;
+  settle_ghosts(h);
   if (n < 0) return fail(h, VOF_EINVAL, "n must be >= 0");
   if (n == 0) return VOF_OK;
   DISPATCH_T(h, (L<double>::rhs<true>(h), jacobi_n<double>(h, n, false)),
@@ -921,7 +954,9 @@ int vof_solve_p_jacobi(vof2d_handle h, int32_t n) {
 }
 int vof_update_uv(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
+  settle_ghosts(h);
   DISPATCH_T(h, L<double>::correct<true>(h), L<float>::correct<true>(h));
+  h->uv_ghosts_dirty = true;
   return ensure_ok(h);
 }
 // A single sweep swaps F with its twin, so field pointers baked into captured step graphs go
@@ -936,6 +971,7 @@ static void sweep_swapped(vof2d_handle h) {
 }
 int vof_fct_x_sweep(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
+  settle_ghosts(h);
   DISPATCH_T(h, (sweep_x<double, false, false>(h)), (sweep_x<float, false, false>(h)));
   h->f_ghosts_dirty = true;
   sweep_swapped(h);
@@ -943,6 +979,7 @@ int vof_fct_x_sweep(vof2d_handle h) {
 }
 int vof_fct_y_sweep(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
+  settle_ghosts(h);
   DISPATCH_T(h, (sweep_y<double, false, false>(h)), (sweep_y<float, false, false>(h)));
   h->f_ghosts_dirty = true;
   sweep_swapped(h);
@@ -960,6 +997,7 @@ int vof_solve_VOF_rudman(vof2d_handle h, int64_t istep) {
 }
 int vof_post_process_f(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
+  settle_ghosts(h);
   DISPATCH_T(h, L<double>::post(h), L<float>::post(h));
   h->f_ghosts_dirty = true;
   return ensure_ok(h);
@@ -977,7 +1015,12 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
     // the end) from a captured graph; the first step after set_init_F / from_numpy / a single verb
     // runs the schedule with the reference's intermediate set_BC calls, eagerly.
     const bool lean = !h->f_ghosts_dirty;
-    if (use_graph && lean) {
+    const bool virt = step_leaves_ghosts_virtual(h);
+    if (!virt) settle_ghosts(h);
+    // a captured step holds the kernels of the handle's regular schedule; the one step after u / v
+    // were written without a set_BC (stored ghost cells must be read as they are) runs eagerly
+    const bool regular = !h->uv_ghosts_dirty;
+    if (use_graph && lean && regular) {
       // graphs bake the field pointers in: one per (parity, which buffer of the F / twin pair holds
       // F).  The two-kernel transport swaps the pair twice per step, the fused one once.
       const int ori = h->fld[fF] == h->f_home ? 0 : 1;
@@ -985,7 +1028,7 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       if (!h->gexec[par][ori]) {
         hipGraph_t graph = nullptr;
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        DISPATCH_T(h, enqueue_step<double>(h, h->istep, true), enqueue_step<float>(h, h->istep, true));
+        DISPATCH_T(h, enqueue_step<double>(h, h->istep, true, virt), enqueue_step<float>(h, h->istep, true, virt));
         HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
         hipError_t e = hipGraphInstantiate(&h->gexec[par][ori], graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
@@ -998,11 +1041,13 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       HIPCHK(h, hipGraphLaunch(h->gexec[par][ori], h->stream));
       if (one_swap) swap_F(h);     // keep the host's view in step with what the replayed kernels did
     } else {
-      DISPATCH_T(h, enqueue_step<double>(h, h->istep, lean), enqueue_step<float>(h, h->istep, lean));
+      DISPATCH_T(h, enqueue_step<double>(h, h->istep, lean, virt), enqueue_step<float>(h, h->istep, lean, virt));
       int rc = ensure_ok(h);
       if (rc) return rc;
     }
     h->f_ghosts_dirty = false;
+    h->uv_ghosts_dirty = false;
+    h->ghosts_virtual = virt;
   }
   return VOF_OK;
 }
@@ -1032,12 +1077,13 @@ int vof_step_phase(vof2d_handle h, int32_t phase) {
   const bool ok = phase == h->next_phase || (phase == VOF_PHASE_TRANSPORT_EDGES && h->next_phase == 2);
   if (!ok) return fail(h, VOF_ESTATE, "vof_step_phase must be called in the order 0, 1, 2 or 0, 1, 3, 4");
   if (phase == 0) {
+    settle_ghosts(h);
     int rc = match_phase_graph_orientation(h);
     if (rc) return rc;
     h->istep += 1;
   }
   h->next_phase = (phase == 2 || phase == 4) ? 0 : phase + 1;
-  if (phase == 2 || phase == 4) h->f_ghosts_dirty = false;   // the phases carry every set_BC of the step
+  if (phase == 2 || phase == 4) h->f_ghosts_dirty = h->uv_ghosts_dirty = false;   // the phases carry every set_BC of the step
   const bool use_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
   if (!use_graph) {
     DISPATCH_T(h, enqueue_phase<double>(h, phase, h->istep), enqueue_phase<float>(h, phase, h->istep));
@@ -1078,6 +1124,7 @@ int vof_set_istep(vof2d_handle h, int64_t istep) {
 int vof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual) {
   if (!h || !residual) return VOF_EINVAL;
   if (n < 1) return fail(h, VOF_EINVAL, "n must be >= 1");
+  settle_ghosts(h);
   HIPCHK(h, hipMemsetAsync(h->d_courant + 1, 0, sizeof(unsigned long long), h->stream));
   if (build_rhs) DISPATCH_T(h, L<double>::rhs<false>(h), L<float>::rhs<false>(h));
   DISPATCH_T(h, jacobi_n<double>(h, n, true), jacobi_n<float>(h, n, true));
@@ -1114,17 +1161,20 @@ int vof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t 
 
 int vof_get_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, void* dst, size_t nbytes) {
   if (!h || !dst) return VOF_EINVAL;
+  settle_ghosts(h);
   int id = field_id(name);
   if (id < 0) return fail(h, VOF_EINVAL, "unknown field name");
   return copy_rows_host(h, id, g0, g1, dst, nbytes, true);
 }
 int vof_set_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, const void* src, size_t nbytes) {
   if (!h || !src) return VOF_EINVAL;
+  settle_ghosts(h);
   int id = field_id(name);
   if (id < 0) return fail(h, VOF_EINVAL, "unknown field name");
   int rc = copy_rows_host(h, id, g0, g1, const_cast<void*>(src), nbytes, false);
   if (rc == VOF_OK && id == fF) rc = copy_rows_host(h, fF2, g0, g1, const_cast<void*>(src), nbytes, false);
   if (id == fF || id == fF2) h->f_ghosts_dirty = true;
+  if (id == fU || id == fV) h->uv_ghosts_dirty = true;
   return rc;
 }
 int vof_get_field(vof2d_handle h, const char* name, void* dst, size_t nbytes) {
@@ -1137,6 +1187,7 @@ int vof_set_field(vof2d_handle h, const char* name, const void* src, size_t nbyt
 }
 int vof_field_view(vof2d_handle h, const char* name, void** base, int64_t* pitch, int64_t* col0, int64_t* nrows) {
   if (!h) return VOF_EINVAL;
+  settle_ghosts(h);
   int id = field_id(name);
   if (id < 0) return fail(h, VOF_EINVAL, "unknown field name");
   if (base) *base = h->fld[id];
@@ -1147,6 +1198,8 @@ int vof_field_view(vof2d_handle h, const char* name, void** base, int64_t* pitch
 }
 int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t g0, int32_t g1) {
   if (!dst || !src) return VOF_EINVAL;
+  settle_ghosts(dst);
+  settle_ghosts(src);
   int id = field_id(name);
   if (id < 0) return fail(dst, VOF_EINVAL, "unknown field name");
   if (dst->d.ny != src->d.ny || dst->d.nx != src->d.nx || dst->d.dtype != src->d.dtype)
@@ -1167,6 +1220,10 @@ int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t 
     HIPCHK(dst, hipMemcpyAsync(reinterpret_cast<char*>(dst->fld[fF2]) + off_d,
                                reinterpret_cast<char*>(src->fld[fF]) + off_s, bytes, hipMemcpyDeviceToDevice,
                                dst->stream));
+  if (dst->g.wall_lo && dst->g.wall_hi) {  // a full domain: the rows' neighbours' ghost cells may no longer mirror them
+    if (id == fF) dst->f_ghosts_dirty = true;
+    if (id == fU || id == fV) dst->uv_ghosts_dirty = true;
+  }
   return VOF_OK;
 }
 
@@ -1186,6 +1243,7 @@ static int vis_scratch(vof2d_handle h, size_t bytes) {
 }
 int vof_get_vis_field(vof2d_handle h, const char* which, void* dst, size_t nbytes) {
   if (!h || !which || !dst) return VOF_EINVAL;
+  settle_ghosts(h);
   if (!(h->g.wall_lo && h->g.wall_hi)) return fail(h, VOF_ESTATE, "display fields need a full-domain handle");
   int mode = !strcmp(which, "vof") ? 0 : !strcmp(which, "u") ? 1 : !strcmp(which, "v") ? 2 : !strcmp(which, "vnorm") ? 3 : -1;
   if (mode < 0) return fail(h, VOF_EINVAL, "display field must be vof, u, v or vnorm");
@@ -1207,6 +1265,7 @@ int vof_get_vis_field(vof2d_handle h, const char* which, void* dst, size_t nbyte
 }
 int vof_interp_velocity(vof2d_handle h, void* dst, size_t nbytes) {
   if (!h || !dst) return VOF_EINVAL;
+  settle_ghosts(h);
   if (!(h->g.wall_lo && h->g.wall_hi)) return fail(h, VOF_ESTATE, "interp_velocity needs a full-domain handle");
   const size_t bytes = (size_t)2 * (h->g.nx + 2) * (h->g.ny + 2) * h->esz;
   if (nbytes != bytes) return fail(h, VOF_EINVAL, "buffer must be (nx+2, ny+2, 2) of the field dtype");
@@ -1233,9 +1292,10 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
     destroy_graphs(h);
     return VOF_OK;
   }
+  settle_ghosts(h);
   if (!strcmp(name, "jacobi_tb") || !strcmp(name, "jacobi_tb_rows") || !strcmp(name, "momentum_rows") ||
       !strcmp(name, "fuse_momentum") || !strcmp(name, "fuse_correct") || !strcmp(name, "fuse_transport") ||
-      !strcmp(name, "fctx_rows") ||
+      !strcmp(name, "virtual_ghosts") || !strcmp(name, "fctx_rows") ||
       !strcmp(name, "fctx_corr_rows") || !strcmp(name, "jacobi_tb_narrow")) {  // tuning knobs
     if (!strcmp(name, "jacobi_tb")) h->tb = (int)value;
     else if (!strcmp(name, "fctx_rows")) h->fctx_rows = (int)value;
@@ -1245,6 +1305,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
     else if (!strcmp(name, "momentum_rows")) h->mom_rows = (int)value;
     else if (!strcmp(name, "fuse_correct")) h->fuse_correct = (int)value;
     else if (!strcmp(name, "fuse_transport")) h->fuse_transport = (int)value;
+    else if (!strcmp(name, "virtual_ghosts")) h->virtual_ghosts = (int)value;
     else h->fuse_momentum = (int)value;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     destroy_graphs(h);
@@ -1326,8 +1387,12 @@ int vof_profile_steps(vof2d_handle h, int64_t nsteps) {
     while (done + batch < nsteps && h->timed + per_step <= vof2d_ctx::kMaxTimed) {
       h->istep += 1;
       const bool lean = !h->f_ghosts_dirty;
-      DISPATCH_T(h, enqueue_step<double>(h, h->istep, lean), enqueue_step<float>(h, h->istep, lean));
+      const bool virt = step_leaves_ghosts_virtual(h);
+      if (!virt) settle_ghosts(h);
+      DISPATCH_T(h, enqueue_step<double>(h, h->istep, lean, virt), enqueue_step<float>(h, h->istep, lean, virt));
       h->f_ghosts_dirty = false;
+      h->uv_ghosts_dirty = false;
+      h->ghosts_virtual = virt;
       ++batch;
     }
     const int launches = h->timed;
@@ -1413,6 +1478,7 @@ int vof_comm_get_unique_id(void* id) {
 int vof_comm_init(vof2d_handle h, const void* id, int32_t rank, int32_t world, int32_t flags) {
   if (!h || !id || world < 1 || rank < 0 || rank >= world) return VOF_EINVAL;
   if (h->comm) return fail(h, VOF_ESTATE, "vof_comm_init: the handle already has a communicator");
+  settle_ghosts(h);
   Rccl* r = rccl();
   if (!r) return fail(h, VOF_ESTATE, "RCCL (librccl.so.1) could not be loaded");
   const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
@@ -1476,6 +1542,7 @@ int vof_comm_exchange(vof2d_handle h, uint32_t field_mask) {
   if (!h->comm) return fail(h, VOF_ESTATE, "vof_comm_init has not been called");
   if (!field_mask_ok(field_mask)) return fail(h, VOF_EINVAL, "field_mask: VOF_XCHG_F | _U | _V | _P");
   HIPCHK(h, hipSetDevice(h->device));
+  settle_ghosts(h);
   int rc = comm_post(h, field_mask);
   return rc ? rc : comm_join(h);
 }
@@ -1518,6 +1585,7 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
   HIPCHK(h, hipSetDevice(h->device));
   const bool want_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
   {
+    settle_ghosts(h);
     int rc0 = match_phase_graph_orientation(h);
     if (rc0) return rc0;
   }

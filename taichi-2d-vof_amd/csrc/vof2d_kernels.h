@@ -39,7 +39,7 @@ struct WaveTimer {
 #else
 struct WaveTimer { __device__ __forceinline__ WaveTimer(int) {} };
 #endif
-enum : int { WT_MOMENTUM = 0, WT_JACOBI_TB = 3, WT_FCT_X = 5, WT_FCT_Y = 6, WT_JACOBI = 2 };  // = KernelId of the runtime
+enum : int { WT_MOMENTUM = 0, WT_JACOBI_TB = 3, WT_FCT_X = 5, WT_FCT_Y = 6, WT_JACOBI = 2, WT_TRANSPORT = 12 };  // = KernelId of the runtime
 template <typename T, int V>
 struct Row {  // one row of a wave tile as seen by a lane: j0-1 | j0..j0+V-1 | j0+V
   T l;
@@ -701,11 +701,29 @@ __device__ __forceinline__ bool row_flat(const Row<T, V>& w) {
   return f;
 }
 
+// set_BC's ghost columns (2dvof.py:164-174: [i,0] = [i,1], [i,ny+1] = [i,ny]) applied to a loaded
+// row window instead of to memory: a lane holds j0-1 | j0..j0+V-1 | j0+V, so the source column is
+// always in the same lane.
+template <typename T, int V>
+__device__ __forceinline__ void mirror_ghost_cols(Row<T, V>& w, int j0, int ny) {
+  if (j0 - 1 == 0) w.l = w.c[0];
+#pragma unroll
+  for (int q = 0; q < V; ++q)
+    if (j0 + q == 0) w.c[q] = q == V - 1 ? w.r : w.c[q + 1];
+#pragma unroll
+  for (int q = 0; q < V; ++q)
+    if (j0 + q == ny + 1) w.c[q] = q == 0 ? w.l : w.c[q - 1];
+  if (j0 + V == ny + 1) w.r = w.c[V - 1];
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* __restrict__ F,
                                                    const T* __restrict__ u, const T* __restrict__ v,
                                                    T* __restrict__ us, T* __restrict__ vs, T* __restrict__ rhs,
-                                                   int R, int ntt) {
+                                                   int R, int ntt, int virt) {
+  // virt (full-domain fused steps, DESIGN.md "virtual ghosts"): the previous step did not run
+  // set_BC; the ghost cells this kernel reads -- F's ghost rows and columns, v's ghost rows, u's
+  // ghost columns -- are formed from the interior cells set_BC would have copied (:164-189).
   constexpr int W = 64 * V;
   constexpr int H = ((2 + V - 1) / V) * V;
   WaveTimer wt_(WT_MOMENTUM);
@@ -725,10 +743,19 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   bool dom[V];
 #pragma unroll
   for (int q = 0; q < V; ++q) dom[q] = (j0 + q) >= 1 && (j0 + q) <= ny;
+  const bool vlo = virt && g.wall_lo, vhi = virt && g.wall_hi;
   auto rowptr = [&](const T* base, int r) {
     const int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
     return base + (size_t)(rc - g.row_lo) * (size_t)g.pitch + (size_t)(g.col0 + j0);
   };
+  // ghost rows 0 / nx+1 of F and v mirror rows 1 / nx (:176-189); u's are stored (u[nx+1] = 0)
+  auto mirrow = [&](int r) { return (vlo && r == 0) ? 1 : ((vhi && r == g.nx + 1) ? g.nx : r); };
+  const bool edge_cols = virt && (c0 - 1 <= 0 || c0 + W >= ny + 1);   // wave-uniform: the tile holds a ghost column
+  // (the ghost columns are mirrored when a row is taken into use, not when it is loaded: the
+  // prefetched rows stay in flight for a whole iteration)
+  auto load_F = [&](Row<T, V>& w, int r) { load_row<T, V>(w, rowptr(F, mirrow(r))); };
+  auto load_u = [&](Row<T, V>& w, int r) { load_row<T, V>(w, rowptr(u, r)); };
+  auto load_v = [&](Row<T, V>& w, int r) { load_row<T, V>(w, rowptr(v, mirrow(r))); };
   // windows; index names are relative to the newest F row r of the current iteration
   Row<T, V> F2, F1;            // F rows r-2, r-1 (become r-3.. after the shift)
   T F3c[V];                    // F row r-3, centre columns
@@ -738,25 +765,36 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   T us3[V], vs3[V];            // u*, v* row r-3
   T rho3[V];                   // rho(F) row r-3 (rho is a pure function of F[i,j], :201-202)
   const int r0 = ra - 1, r1 = rb + 3;
-  load_row<T, V>(F2, rowptr(F, r0 - 2));
-  load_row<T, V>(F1, rowptr(F, r0 - 1));
-  load_row<T, V>(u3, rowptr(u, r0 - 3));
-  load_row<T, V>(u2, rowptr(u, r0 - 2));
-  load_row<T, V>(v3, rowptr(v, r0 - 3));
-  load_row<T, V>(v2, rowptr(v, r0 - 2));
+  load_F(F2, r0 - 2);
+  load_F(F1, r0 - 1);
+  load_u(u3, r0 - 3);
+  load_u(u2, r0 - 2);
+  load_v(v3, r0 - 3);
+  load_v(v2, r0 - 2);
+  if (edge_cols) {
+    mirror_ghost_cols<T, V>(F2, j0, ny);
+    mirror_ghost_cols<T, V>(F1, j0, ny);
+    mirror_ghost_cols<T, V>(u3, j0, ny);
+    mirror_ghost_cols<T, V>(u2, j0, ny);
+  }
 #pragma unroll
   for (int q = 0; q < V; ++q) F3c[q] = mx2[q] = mx3[q] = my2[q] = k3[q] = us3[q] = vs3[q] = rho3[q] = (T)0;
   bool flat2 = row_flat<T, V>(F2), flat1 = row_flat<T, V>(F1), flat0;  // rows r-2, r-1, r all-equal tests
   Row<T, V> Fn, un, vn;  // prefetched: F row r, u / v row r-1
-  load_row<T, V>(Fn, rowptr(F, r0));
-  load_row<T, V>(un, rowptr(u, r0 - 1));
-  load_row<T, V>(vn, rowptr(v, r0 - 1));
+  load_F(Fn, r0);
+  load_u(un, r0 - 1);
+  load_v(vn, r0 - 1);
   for (int r = r0; r <= r1; ++r) {
-    const Row<T, V> F0 = Fn, u1 = un, v1 = vn;
+    Row<T, V> F0 = Fn, u1 = un;
+    const Row<T, V> v1 = vn;
+    if (edge_cols) {
+      mirror_ghost_cols<T, V>(F0, j0, ny);
+      mirror_ghost_cols<T, V>(u1, j0, ny);
+    }
     if (r < r1) {
-      load_row<T, V>(Fn, rowptr(F, r + 1));
-      load_row<T, V>(un, rowptr(u, r));
-      load_row<T, V>(vn, rowptr(v, r));
+      load_F(Fn, r + 1);
+      load_u(un, r);
+      load_v(vn, r);
     }
     // ---- N: normals of row r-1 (:285-306)
     const bool okN = (r - 1) >= ilo && (r - 1) <= ihi;
@@ -1659,6 +1697,7 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
                                                     T* __restrict__ Uo, T* __restrict__ Vo,
                                                     unsigned long long* __restrict__ courant) {
   constexpr int W = 64 * V, STRIDE = W - 8;
+  WaveTimer wt_(WT_TRANSPORT);
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int tj = wave % nty, ch = wave / nty;

@@ -523,3 +523,79 @@ def test_random_configurations_match_oracle(hip_api, oracle_api):
             assert np.array_equal(x, y, equal_nan=True), ctx + " | " + diff_report(x, y, f)
         assert a.get_counter("courant_violations") == b.get_counter("courant_violations"), ctx
         a.close(); b.close()
+
+
+READERS = ("get_F", "get_u", "get_v", "get_p", "rows_p", "vis", "interp", "copy_rows", "cal_nu_rho", "get_normal_young",
+           "advect_upwind", "solve_p_jacobi", "update_uv", "fct_x_sweep", "fct_y_sweep", "post_process_f", "residual",
+           "phases", "set_BC", "set_field", "set_param")
+
+
+@pytest.mark.parametrize("reader", READERS)
+def test_virtual_ghosts_are_settled_before_anything_else_looks(hip_api, oracle_api, reader):
+    """The fused full-domain step leaves out its set_BC launch (k_momentum forms the ghost cells it
+    reads); every other entry point must see -- and leave -- exactly what the reference's three
+    set_BC calls per step produce.  Each reader follows an odd and an even number of fused steps."""
+    nx, ny = 70, 141
+    for steps in (3, 4):
+        a, b = engine(hip_api, nx, ny, "f64", "f32", ic=3), engine(oracle_api, nx, ny, "f64", "f32", ic=3)
+        a.step(steps); b.step(steps)
+        assert a.get_param("fuse_transport") == 1.0
+        names = STATE
+        if reader.startswith("get_"):
+            f = reader[4:]
+            if f in STATE:
+                assert same(a.get(f), b.get(f)), diff_report(a.get(f), b.get(f), f)
+                continue
+        if reader == "rows_p":
+            assert same(a.get("p", (0, 2)), b.get("p", (0, 2)))
+            assert same(a.get("p", (nx - 1, nx + 1)), b.get("p", (nx - 1, nx + 1)))
+            continue
+        if reader == "vis":
+            for w in ("vof", "u", "v", "vnorm"):
+                assert same(a.vis_field(w), b.vis_field(w)), w
+            continue
+        if reader == "interp":
+            assert same(a.interp_velocity(), b.interp_velocity())
+            continue
+        if reader == "copy_rows":
+            c = engine(hip_api, nx, ny, "f64", "f32")
+            for f in STATE:
+                c.copy_rows_from(a, f, 0, nx + 1)
+            assert_fields_same(c, b, STATE, ctx="copy_rows after %d fused steps" % steps)
+            continue
+        if reader == "residual":
+            ra, rb_ = a.solve_p_residual(1e-30, 6, 3), b.solve_p_residual(1e-30, 6, 3)
+            assert ra == rb_
+        elif reader == "phases":
+            for e in (a, b):
+                if e is a:
+                    for ph in (0, 1, 2):
+                        e.step_phase(ph)
+                else:
+                    e.step(1)
+        elif reader == "set_field":
+            u = b.get("u")
+            u[5:9, 3:8] += 0.01
+            for e in (a, b):
+                e.set("u", u)
+        elif reader == "set_param":
+            for e in (a, b):
+                e.set_param("sigma", 0.01)
+        else:
+            # the fused step keeps rho, nu, mx, my, kappa in registers: a verb that reads the stored
+            # arrays gets the reference's preceding verbs first (2dvof.py:513-517)
+            prefix = {"advect_upwind": ("cal_nu_rho", "get_normal_young"), "solve_p_jacobi": ("cal_nu_rho",),
+                      "update_uv": ("cal_nu_rho",)}.get(reader, ())
+            for e in (a, b):
+                for verb in prefix + (reader,):
+                    if verb == "solve_p_jacobi":
+                        e.solve_p_jacobi(3)
+                    else:
+                        getattr(e, verb)()
+            names = STATE + {"cal_nu_rho": ("rho", "nu"), "get_normal_young": ("mx", "my", "kappa"),
+                             "advect_upwind": ("u_star", "v_star", "rho", "nu", "mx", "my", "kappa"),
+                             "solve_p_jacobi": ("rho", "nu"), "update_uv": ("rho", "nu")}.get(reader, ())
+        assert_fields_same(a, b, names, ctx="%s after %d fused steps" % (reader, steps))
+        # and the run goes on identically (fused steps again, ghosts virtual again)
+        a.step(3); b.step(3)
+        assert_fields_same(a, b, STATE, ctx="3 more steps after %s" % reader)

@@ -9,7 +9,7 @@ import argparse, ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "taichi-2d-vof_amd"))
-KIDS = {"k_momentum": 0, "k_jacobi_tb": 3, "k_fct_x": 5, "k_fct_y": 6}
+KIDS = {"k_momentum": 0, "k_jacobi_tb": 3, "k_transport": 12, "k_fct_x": 5, "k_fct_y": 6}
 
 def main():
     ap = argparse.ArgumentParser()
@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--n", type=int, default=1); ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--at", default="20,200", help="step numbers at which to sample")
     ap.add_argument("--ic", type=int, default=1)
+    ap.add_argument("--extra", type=int, default=2, help="steps run per kernel before its stamps are read (1 or 2: which sweep order comes last)")
     a = ap.parse_args()
     from vof2d import _abi
     from vof2d.engine import Engine, make_desc
@@ -40,7 +41,7 @@ def main():
         for name, kid in KIDS.items():
             h = e._h
             assert dbg(h, kid, None, cap) == 0
-            e.step(2); done += 2   # both sweep orders; the later launch of a kernel overwrites the earlier
+            e.step(a.extra); done += a.extra   # the later launch of a kernel overwrites the earlier
             out = np.zeros((cap, 2), np.uint64)
             assert dbg(h, kid, out.ctypes.data, cap) == 0
             m = out[:, 1] > 0
