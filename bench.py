@@ -62,9 +62,11 @@ def parse():
                          "kills it and tries the next carrier (default 300 + 0.01 per step; three times that for torch)")
     ap.add_argument("--no-supervisor", action="store_true", help="N > 1: run in this process, no watchdog / fallback")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3],
+    ap.add_argument("--overlap", type=int, default=4, choices=[0, 1, 2, 3, 4],
                     help="N > 1: 0 = one exchange after the step, 1 = each field as soon as it is final, "
-                         "2 = 1 + F's edge bands first, 3 = p, u, v together after the first sweep (vof_step_exchange)")
+                         "2 = 1 + F's edge bands first, 3 = p, u, v together after the first sweep, 4 = fused transport "
+                         "kernel on the edge bands, all four fields in one group under the transport of the other rows "
+                         "(vof_step_exchange)")
     return ap.parse_args()
 
 
@@ -393,7 +395,8 @@ def main():
     kernels_us = {k: round(v[0], 2) for k, v in prof.items()}
 
     try:
-        one_kernel_transport = bool(eng.get_param("fuse_transport")) and exchange == "none"
+        one_kernel_transport = (bool(eng.get_param("fuse_transport")) and exchange == "none") or \
+                               (exchange == "native" and a.overlap == 4)
     except Exception:
         one_kernel_transport = False
     ARRAYS_PER_STEP = ARRAYS_PER_STEP_FULL if one_kernel_transport else ARRAYS_PER_STEP_STRIP

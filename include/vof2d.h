@@ -196,7 +196,10 @@ int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep);
  *                           overlap = 0: one exchange of all four after the step; overlap = 2:
  *                           like 1 with phase 2 split (VOF_PHASE_TRANSPORT_EDGES, send/recv F,
  *                           VOF_PHASE_TRANSPORT_REST); overlap = 3: p, u, v in one group after
- *                           phase 1, F after phase 2 (one fork less).  After the first step (RCCL connects on
+ *                           phase 1, F after phase 2 (one fork less); overlap = 4: update_uv and
+ *                           both sweeps as ONE kernel (k_transport), first on the edge bands, then
+ *                           send/recv p, u, v, F in one group, and the same kernel on the remaining
+ *                           rows while they travel.  After the first step (RCCL connects on
  *                           first use) a step and its exchanges are one hipGraph launch; if the
  *                           RCCL at hand cannot be captured the launches stay eager.  The host
  *                           does not block

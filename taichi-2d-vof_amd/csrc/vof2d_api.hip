@@ -144,12 +144,13 @@ struct vof2d_ctx {
   int tb_rows = 0;      // rows per wave chunk of the fused kernel (0 = heuristic)
   int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
   int tb_general = 0;   // force the general (dx != dy) fused Jacobi kernel
-  int tb_narrow = 1;    // allow the one-column-per-lane fused Jacobi kernel on thin strips
+  int tb_narrow = 0;    // 1: the one-column-per-lane fused Jacobi kernel on thin, wide strips (see jacobi_tb)
   int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = heuristic, at most 16)
   int fctx_corr_rows = 0;  // ... of its update_uv-carrying form (0 = same rule)
   int fuse_momentum = 1;
   int fuse_correct = 1; // vof_step on a full domain: update_uv inside the first FCT sweep
   int fuse_transport = 1;  // ... and both FCT sweeps in one kernel (k_transport), full domains only
+  int band_rows = 4;       // rows per wave chunk of the edge-band launch of the fused transport (strips)
   int virtual_ghosts = 1;  // ... without the step's set_BC launch (k_momentum forms the ghost cells it reads)
   void* f_home = nullptr;  // the buffer fld[fF] pointed to at creation (orientation of the F / twin pair)
   int phase_graph_ori = 0; // orientation the gphase / gxchg graphs were captured in
@@ -175,7 +176,7 @@ struct vof2d_ctx {
   hipStream_t cstream = nullptr; // RCCL's kernels run here, next to the compute stream
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr};  // one per exchange of a step (graph capture forks)
-  hipGraphExec_t gxchg[2][4] = {};   // whole step + exchanges, [istep parity][overlap mode]
+  hipGraphExec_t gxchg[2][5][2] = {};   // whole step + exchanges, [istep parity][overlap mode][F / twin orientation]
   int xchg_graph = 1;                // 0 after a failed capture (or VOF2D_XCHG_GRAPH=0): eager launches
   int64_t xchg_steps = 0;            // steps run by vof_step_exchange (the first one is always eager)
   int64_t xchg_graph_steps = 0;      // ... of which replayed from a captured graph
@@ -414,11 +415,12 @@ struct L {
     int ntt = 0;
     const int R = jacobi_tb_plan<TS, V>(h, sq, ntt);
     // Thin, wide strips (what strong scaling produces: 1056 x 8192 per GPU at 8 GPUs): the variant
-    // with one column per lane needs 71 VGPRs, so 7 waves/SIMD are resident instead of 3, and that
-    // is worth more there than the wider tile: 70 vs 77 us per launch.  (Planning it for fewer
-    // resident waves and longer chunks -- fewer lead-in rows -- is slower: 75 / 87 / 100 us for
-    // 5 / 4 / 3 waves per SIMD.)  On full grids two columns per lane win (4096^2: 89 vs 103 us,
-    // 2048^2: 30 vs 35 us).  Square cells, five sweeps, fp64 only.
+    // with one column per lane needs 71 VGPRs, so 7 waves/SIMD are resident instead of 3.  It wins
+    // only while the tiny-value front of the pressure iteration crosses the strip (steps ~65-800 of
+    // a run started from p = 0: 71 vs 78-82 us per launch, the slow waves are smaller); before and
+    // after that two columns per lane are faster (49-53 vs 59-69 us per launch, 384 vs 401 us per
+    // strip step), so it is opt-in (jacobi_tb_narrow = 1).  On full grids two columns per lane win
+    // throughout (4096^2: 89 vs 103 us, 2048^2: 30 vs 35 us).  Square cells, five sweeps, fp64 only.
     if constexpr (sizeof(T) == 8 && TS == 5 && V == 2) {
       if (sq && R < 32 && ntt >= 48 && h->tb_rows <= 0 && h->tb_narrow != 0) {
         int ntt1 = 0;
@@ -457,12 +459,15 @@ struct L {
            (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
   }
   // update_uv + both sweeps + post_process_f in one pass (k_transport); reads fld[fF], writes fld[fF2]
+  // rows [a, b] (and [a2, b2] if b2 >= a2) of the output; 0, 0: all computable rows
   template <bool YFIRST>
-  static void transport(vof2d_ctx* h) {
-    const int R = h->fctx_corr_rows > 0 ? h->fctx_corr_rows : chunk_rows(h, h->nty, 4, 16);
-    launch(h, kTransport, k_transport<T, V, YFIRST>, dim3(blocks_for(h, h->nty, R)), 0, h->g, C(h),
+  static void transport(vof2d_ctx* h, int a = 0, int b = 0, int a2 = 1, int b2 = 0, int Rforce = 0) {
+    if (a == 0 && b == 0) { a = h->g.ilo; b = h->g.ihi; }
+    const int R = Rforce > 0 ? Rforce : (h->fctx_corr_rows > 0 ? h->fctx_corr_rows : chunk_rows(h, h->nty, 4, 16));
+    const long chunks = (b - a + R) / R + (b2 >= a2 ? (b2 - a2 + R) / R : 0);
+    launch(h, kTransport, k_transport<T, V, YFIRST>, dim3((unsigned)((chunks * h->nty + 3) / 4)), 0, h->g, C(h),
            (const T*)F_<T>(h, fF), F_<T>(h, fF2), R, h->nty, (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS),
-           (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant);
+           (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, a, b, a2, b2);
   }
 };
 
@@ -500,6 +505,33 @@ void final_sweep(vof2d_ctx* h, bool along_x, int part) {
   } else {
     if (split) run(in_lo, in_hi, false);
     else if (!band_lo && !band_hi) run(lo, hi, false);  // a full domain has no bands: the rest is everything
+  }
+}
+
+// The fused transport (k_transport) on the owned rows of a strip, all at once or in the two parts
+// of TransportPart: both edge bands in ONE launch, then the rest.
+template <typename T>
+void transport_part(vof2d_ctx* h, bool y_first, int part) {
+  const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
+  const int lo = h->d.own_lo > h->g.ilo ? h->d.own_lo : h->g.ilo, hi = h->d.own_hi < h->g.ihi ? h->d.own_hi : h->g.ihi;
+  const bool band_lo = !h->g.wall_lo, band_hi = !h->g.wall_hi;
+  // the bands are few rows: short chunks, so that the launch is many short-lived waves (2 x 16 rows
+  // of an 8192-wide strip: 31 us with 16-row chunks, see profiles) instead of a few long ones
+  const int Rband = h->band_rows;
+  auto run = [&](int a, int b, int a2, int b2) {
+    if (b < a && b2 < a2) return;
+    if (b < a) { a = a2; b = b2; a2 = 1; b2 = 0; }
+    const int Rf = part == kEdgeBands ? Rband : 0;
+    if (y_first) L<T>::template transport<true>(h, a, b, a2, b2, Rf); else L<T>::template transport<false>(h, a, b, a2, b2, Rf);
+  };
+  const int in_lo = band_lo ? lo + W : lo, in_hi = band_hi ? hi - W : hi;   // strips are >= W rows thick
+  const bool split = in_lo <= in_hi && (band_lo || band_hi);
+  if (part == kAllOwned || !(band_lo || band_hi)) { if (part != kEdgeBands) run(lo, hi, 1, 0); return; }
+  if (part == kEdgeBands) {
+    if (!split) { run(lo, hi, 1, 0); return; }   // the bands meet: everything is edge
+    run(band_lo ? lo : 1, band_lo ? in_lo - 1 : 0, band_hi ? in_hi + 1 : 1, band_hi ? hi : 0);
+  } else if (split) {
+    run(in_lo, in_hi, 1, 0);
   }
 }
 
@@ -569,7 +601,7 @@ void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
 // 0) or zero stencil coefficients, and the first sweep itself stores the wall-face zeros of u, v
 // the second sweep reads.
 template <typename T>
-void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false, bool lean = false) {
+void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false, bool lean = false, bool virt = false) {
   const bool y_first = (istep % 2 == 0);    // :526, :312-318
   const bool corr = h->fuse_correct != 0;
   if (lean && !(corr && h->fuse_momentum)) lean = false;
@@ -577,7 +609,7 @@ void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false
     // cal_nu_rho (:513) is folded into its consumers: rho/nu = f(F[i,j]) recomputed per cell
     if (h->fuse_momentum) {
       // :514, :517 and the (sweep-invariant, BC-independent) rhs of :239-241 in one pass
-      L<T>::momentum(h);
+      L<T>::momentum(h, virt);              // virt: the previous step's set_BC launch was left out (see enqueue_step)
     } else {
       L<T>::normals(h);                     // :514 loop 1
       L<T>::kappa(h);                       // :514 loop 2
@@ -761,8 +793,9 @@ void comm_teardown(vof2d_ctx* h) {
 // everything enqueued on the compute stream so far; the compute stream does not wait (comm_join).
 void destroy_xchg_graphs(vof2d_ctx* h) {
   for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 4; ++b)
-      if (h->gxchg[a][b]) { (void)hipGraphExecDestroy(h->gxchg[a][b]); h->gxchg[a][b] = nullptr; }
+    for (int b = 0; b < 5; ++b)
+      for (int o = 0; o < 2; ++o)
+        if (h->gxchg[a][b][o]) { (void)hipGraphExecDestroy(h->gxchg[a][b][o]); h->gxchg[a][b][o] = nullptr; }
 }
 int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1) {
   Rccl* r = rccl();
@@ -858,6 +891,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   if ((ev = getenv("VOF2D_FUSE_CORRECT"))) h->fuse_correct = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_TRANSPORT"))) h->fuse_transport = atoi(ev);
   if ((ev = getenv("VOF2D_VIRTUAL_GHOSTS"))) h->virtual_ghosts = atoi(ev);
+  if ((ev = getenv("VOF2D_BAND_ROWS")) && atoi(ev) > 0) h->band_rows = atoi(ev);
   if ((ev = getenv("VOF2D_FUSE_MOMENTUM"))) h->fuse_momentum = atoi(ev);
   if ((ev = getenv("VOF2D_MOM_ROWS"))) h->mom_rows = atoi(ev);
 
@@ -964,7 +998,7 @@ int vof_update_uv(vof2d_handle h) {
 static void sweep_swapped(vof2d_handle h) {
   bool any = h->gexec[0][0] || h->gexec[0][1] || h->gexec[1][0] || h->gexec[1][1];
   for (int k = 0; k < 9; ++k) any = any || h->gphase[k];
-  for (int k = 0; k < 8; ++k) any = any || h->gxchg[k / 4][k % 4];
+  for (int k = 0; k < 20; ++k) any = any || h->gxchg[k / 10][(k / 2) % 5][k % 2];
   if (!any) return;
   (void)hipStreamSynchronize(h->stream);
   destroy_graphs(h);
@@ -1051,19 +1085,17 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
   }
   return VOF_OK;
 }
-// The phase and exchange graphs bake the F / twin pointers in and assume the pair returns to the
-// same orientation after every step (two swaps).  vof_step's fused transport swaps once per step,
-// so a handle that mixes the two entry points may arrive here with the pair the other way round:
-// drop those graphs then (they are re-captured on use).
+// The phase graphs bake the F / twin pointers in and assume the pair returns to the same orientation
+// after every step (two swaps).  The fused transport swaps once per step, so a handle that mixes
+// the entry points may arrive here with the pair the other way round: drop those graphs then
+// (they are re-captured on use).  The step and exchange graphs are keyed by the orientation.
 static int match_phase_graph_orientation(vof2d_handle h) {
   const int ori = h->fld[fF] == h->f_home ? 0 : 1;
   if (ori == h->phase_graph_ori) return VOF_OK;
   bool any = false;
   for (int k = 0; k < 9; ++k) any = any || h->gphase[k];
-  for (int k = 0; k < 8; ++k) any = any || h->gxchg[k / 4][k % 4];
   if (any) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    destroy_xchg_graphs(h);
     for (int k = 0; k < 9; ++k)
       if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }
   }
@@ -1295,7 +1327,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
   settle_ghosts(h);
   if (!strcmp(name, "jacobi_tb") || !strcmp(name, "jacobi_tb_rows") || !strcmp(name, "momentum_rows") ||
       !strcmp(name, "fuse_momentum") || !strcmp(name, "fuse_correct") || !strcmp(name, "fuse_transport") ||
-      !strcmp(name, "virtual_ghosts") || !strcmp(name, "fctx_rows") ||
+      !strcmp(name, "virtual_ghosts") || !strcmp(name, "band_rows") || !strcmp(name, "fctx_rows") ||
       !strcmp(name, "fctx_corr_rows") || !strcmp(name, "jacobi_tb_narrow")) {  // tuning knobs
     if (!strcmp(name, "jacobi_tb")) h->tb = (int)value;
     else if (!strcmp(name, "fctx_rows")) h->fctx_rows = (int)value;
@@ -1306,6 +1338,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
     else if (!strcmp(name, "fuse_correct")) h->fuse_correct = (int)value;
     else if (!strcmp(name, "fuse_transport")) h->fuse_transport = (int)value;
     else if (!strcmp(name, "virtual_ghosts")) h->virtual_ghosts = (int)value;
+    else if (!strcmp(name, "band_rows")) h->band_rows = (int)value < 1 ? 1 : (int)value;
     else h->fuse_momentum = (int)value;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     destroy_graphs(h);
@@ -1559,8 +1592,26 @@ int enqueue_step_exchange(vof2d_ctx* h, int mode) {
   // lean phases (no boundary launch inside): the rows travel with whatever ghost columns they
   // have, and one set_bc<u,v,F,p> over all stored rows -- owned and received alike -- follows the
   // join.  Only reached on steps that start with consistent F ghosts (vof_step_exchange).
+  // With virtual ghosts (see enqueue_step) even that launch goes: the rows travel with stale ghost
+  // columns and the next step's k_momentum forms the ones it reads, for owned and received rows alike.
   const bool lean = h->fuse_correct && h->fuse_momentum;
-  enqueue_phase<T>(h, 0, h->istep, false, lean);
+  const bool virt = lean && h->virtual_ghosts;
+  enqueue_phase<T>(h, 0, h->istep, false, lean, virt);
+  if (mode == 4) {
+    // fused transport (update_uv + both sweeps in one pass), edge bands first: p, u, v and F (from
+    // the twin buffer) leave as soon as the bands exist and travel under the transport of the
+    // remaining rows
+    const bool y_first = (h->istep % 2 == 0);
+    transport_part<T>(h, y_first, kEdgeBands);
+    // one group for all four fields: p has been final since the pressure solve, but a separate
+    // fork for it costs more (a 6-12 us gap on the compute queue) than its 1/4 of the bytes
+    if ((rc = comm_post(h, VOF_XCHG_P | VOF_XCHG_F | VOF_XCHG_U | VOF_XCHG_V, /*f_in_twin=*/true, 1))) return rc;
+    transport_part<T>(h, y_first, kRest);
+    swap_F(h);
+    if ((rc = comm_join(h))) return rc;
+    if (!virt) L<T>::template set_bc<BC_ALL>(h);
+    return VOF_OK;
+  }
   if ((mode == 1 || mode == 2) && (rc = comm_post(h, VOF_XCHG_P, false, 0))) return rc;   // p is final
   enqueue_phase<T>(h, 1, h->istep, false, lean);
   if (mode && (rc = comm_post(h, mode == 3 ? (VOF_XCHG_P | VOF_XCHG_U | VOF_XCHG_V) : (VOF_XCHG_U | VOF_XCHG_V), false, 1))) return rc;  // u, v are final
@@ -1573,23 +1624,23 @@ int enqueue_step_exchange(vof2d_ctx* h, int mode) {
     if ((rc = comm_post(h, mode ? VOF_XCHG_F : (VOF_XCHG_F | VOF_XCHG_U | VOF_XCHG_V | VOF_XCHG_P), false, 2))) return rc;
   }
   if ((rc = comm_join(h))) return rc;           // halos complete before the next step
-  if (lean) L<T>::template set_bc<BC_ALL>(h);
+  if (lean && !virt) L<T>::template set_bc<BC_ALL>(h);
   return VOF_OK;
 }
 }  // namespace
 extern "C" {
 int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
-  if (!h || nsteps < 0 || overlap < 0 || overlap > 3) return VOF_EINVAL;
+  if (!h || nsteps < 0 || overlap < 0 || overlap > 4) return VOF_EINVAL;
   if (!h->comm) return fail(h, VOF_ESTATE, "vof_comm_init has not been called");
   if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
   HIPCHK(h, hipSetDevice(h->device));
   const bool want_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
-  {
-    settle_ghosts(h);
-    int rc0 = match_phase_graph_orientation(h);
-    if (rc0) return rc0;
-  }
   for (int64_t s = 0; s < nsteps; ++s) {
+    // the captured step leaves the ghost cells virtual (if the handle does that at all); every other
+    // way through this loop wants them settled first
+    const bool captured_path = want_graph && h->xchg_graph && h->xchg_steps > 0 && !h->f_ghosts_dirty && !h->uv_ghosts_dirty;
+    const bool virt = captured_path && h->fuse_correct && h->fuse_momentum && h->virtual_ghosts;
+    if (!virt) settle_ghosts(h);
     h->istep += 1;
     const int par = (int)(h->istep & 1);
     int rc;
@@ -1598,8 +1649,10 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
     // compute stream, the send/recv groups forked onto the communication stream, the join -- is
     // one hipGraph per (sweep order, mode): one launch per step instead of four graph launches
     // and three RCCL group launches (~100 us of host time each).
-    if (want_graph && h->xchg_graph && h->xchg_steps > 0 && !h->f_ghosts_dirty) {
-      if (!h->gxchg[par][overlap]) {
+    const int ori = h->fld[fF] == h->f_home ? 0 : 1;
+    const bool one_swap = overlap == 4;   // the fused transport swaps the F / twin pair once per step
+    if (captured_path) {
+      if (!h->gxchg[par][overlap][ori]) {
         void* keep[NFIELDS];
         memcpy(keep, h->fld, sizeof(keep));
         hipGraph_t graph = nullptr;
@@ -1613,36 +1666,40 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
           e = hipStreamEndCapture(h->stream, &graph);
           if (dbg) fprintf(stderr, "[vof2d]   capture ended: %s\n", hipGetErrorString(e));
         }
-        if (e == hipSuccess && rc == VOF_OK && graph) e = hipGraphInstantiate(&h->gxchg[par][overlap], graph, nullptr, nullptr, 0);
+        if (e == hipSuccess && rc == VOF_OK && graph) e = hipGraphInstantiate(&h->gxchg[par][overlap][ori], graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
-        if (e != hipSuccess || rc != VOF_OK || !h->gxchg[par][overlap]) {
+        if (one_swap) memcpy(h->fld, keep, sizeof(keep));   // capturing swapped the host's view; the replay below redoes it
+        if (e != hipSuccess || rc != VOF_OK || !h->gxchg[par][overlap][ori]) {
           // this RCCL / runtime cannot capture the exchange: keep going with eager launches
           (void)hipGetLastError();
           memcpy(h->fld, keep, sizeof(keep));
-          h->gxchg[par][overlap] = nullptr;
+          h->gxchg[par][overlap][ori] = nullptr;
           h->xchg_graph = 0;
           if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] exchange graph capture failed (%s / %s): eager\n", hipGetErrorString(e), h->err);
         }
       }
-      if (h->gxchg[par][overlap]) {
-        HIPCHK(h, hipGraphLaunch(h->gxchg[par][overlap], h->stream));
+      if (h->gxchg[par][overlap][ori]) {
+        HIPCHK(h, hipGraphLaunch(h->gxchg[par][overlap][ori], h->stream));
+        if (one_swap) swap_F(h);
         h->xchg_steps += 1;
         h->xchg_graph_steps += 1;
+        h->ghosts_virtual = virt;
         continue;
       }
     }
     h->istep -= 1;  // vof_step_phase(0) advances it
+    const int eo = overlap == 4 ? 1 : overlap;   // eager steps (the first of a communicator, ...) of mode 4 run as mode 1
     if ((rc = vof_step_phase(h, 0))) return rc;
-    if ((overlap == 1 || overlap == 2) && (rc = comm_post(h, VOF_XCHG_P))) return rc;
+    if ((eo == 1 || eo == 2) && (rc = comm_post(h, VOF_XCHG_P))) return rc;
     if ((rc = vof_step_phase(h, 1))) return rc;
-    if (overlap && (rc = comm_post(h, overlap == 3 ? (VOF_XCHG_P | VOF_XCHG_U | VOF_XCHG_V) : (VOF_XCHG_U | VOF_XCHG_V)))) return rc;
-    if (overlap == 2) {
+    if (eo && (rc = comm_post(h, eo == 3 ? (VOF_XCHG_P | VOF_XCHG_U | VOF_XCHG_V) : (VOF_XCHG_U | VOF_XCHG_V)))) return rc;
+    if (eo == 2) {
       if ((rc = vof_step_phase(h, VOF_PHASE_TRANSPORT_EDGES))) return rc;
       if ((rc = comm_post(h, VOF_XCHG_F, /*f_in_twin=*/true))) return rc;
       if ((rc = vof_step_phase(h, VOF_PHASE_TRANSPORT_REST))) return rc;
     } else {
       if ((rc = vof_step_phase(h, 2))) return rc;
-      if ((rc = comm_post(h, overlap ? VOF_XCHG_F : (VOF_XCHG_F | VOF_XCHG_U | VOF_XCHG_V | VOF_XCHG_P)))) return rc;
+      if ((rc = comm_post(h, eo ? VOF_XCHG_F : (VOF_XCHG_F | VOF_XCHG_U | VOF_XCHG_V | VOF_XCHG_P)))) return rc;
     }
     if ((rc = comm_join(h))) return rc;
     h->xchg_steps += 1;

@@ -1695,7 +1695,11 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
                                                     int R, int nty, const T* __restrict__ us,
                                                     const T* __restrict__ vs, const T* __restrict__ p,
                                                     T* __restrict__ Uo, T* __restrict__ Vo,
-                                                    unsigned long long* __restrict__ courant) {
+                                                    unsigned long long* __restrict__ courant, int rfirst, int rlast,
+                                                    int rfirst2, int rlast2) {
+  // rows [rfirst, rlast] and (optionally, rlast2 >= rfirst2) [rfirst2, rlast2] are produced -- all
+  // computable rows of a full domain; on a strip the owned rows, or first only their two edge
+  // bands (what the neighbours wait for) and then the rest.  The sweeps' domain stays [ilo, ihi].
   constexpr int W = 64 * V, STRIDE = W - 8;
   WaveTimer wt_(WT_TRANSPORT);
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1704,9 +1708,11 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
   const int c0 = -3 + tj * STRIDE;
   const int j0 = c0 + lane * V;
   const int ilo = g.ilo, ihi = g.ihi, nx = g.nx, ny = g.ny;
-  const int ra = ilo + ch * R;
-  if (ra > ihi) return;  // wave-uniform
-  const int rb = ra + R - 1 < ihi ? ra + R - 1 : ihi;
+  const int nch1 = (rlast - rfirst + R) / R;   // chunks of the first range
+  const int lo = ch < nch1 ? rfirst : rfirst2, hi = ch < nch1 ? rlast : rlast2;
+  const int ra = lo + (ch < nch1 ? ch : ch - nch1) * R;
+  if (ra > hi) return;  // wave-uniform
+  const int rb = ra + R - 1 < hi ? ra + R - 1 : hi;
   const int jlo = c0 + 4 > 1 ? c0 + 4 : 1;
   const int jhi = c0 + W - 5 < ny ? c0 + W - 5 : ny;
   auto rowptr = [&](const T* base, int r) {

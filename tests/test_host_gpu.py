@@ -154,12 +154,15 @@ def test_native_rccl_exchange_loopback(hip_api):
     # (between real neighbours they are rewritten with identical values), so rows near the edges
     # depend on timing here.  Deterministic and checked: every halo ends up holding the final
     # owned rows next to it, and rows deeper than one step's dependency cone equal the reference.
-    for mode in (1, 2, 3, 1, 2, 3, 2, 1):
+    for mode in (1, 2, 3, 1, 2, 3, 2, 1, 4, 4, 4, 1, 4, 4, 2):   # 4: fused transport, one F / twin swap per step
         for f in ("F", "u", "v", "p"):
             ref.set(f, e.get(f, rows), rows)
         ref.istep = e.istep
         e.step_exchange(1, mode)
-        ref.step_phase(0); loop(("p",)); ref.step_phase(1); loop(("u", "v")); ref.step_phase(2); loop(("F",))
+        if mode == 4:   # all four fields together once the edge bands of the fused transport exist
+            ref.step_phase(0); ref.step_phase(1); ref.step_phase(2); loop(("p", "u", "v", "F"))
+        else:
+            ref.step_phase(0); loop(("p",)); ref.step_phase(1); loop(("u", "v")); ref.step_phase(2); loop(("F",))
         for f in ("F", "u", "v", "p"):
             got = e.get(f, rows)
             assert np.array_equal(got[lo - W:lo], got[lo:lo + W], equal_nan=True), (f, mode)

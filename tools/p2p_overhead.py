@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--n", type=int, default=8); ap.add_argument("--nx", type=int, default=8192)
     ap.add_argument("--ny", type=int, default=8192); ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--dt", type=float, default=1e-6)
-    ap.add_argument("--modes", default="compute,native-overlap,native-two,native-after")
+    ap.add_argument("--modes", default="compute,native-overlap,native-two,native-after,native-fused")
     ap.add_argument("--rounds", type=int, default=2)
     a = ap.parse_args()
     modes = a.modes.split(",")
@@ -72,6 +72,8 @@ def main():
             e.step_exchange(n, 3)
         elif mode == "native-after":
             e.step_exchange(n, 0)
+        elif mode == "native-fused":
+            e.step_exchange(n, 4)
         else:
             with torch.cuda.stream(stream):
                 for _ in range(n):
