@@ -1,3 +1,4 @@
+# Collects what profiles/r01g_* is made of (run on the GPU box through gpurun; summaries: tools/summarize_profiles.py).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-scaling-reference"
 rm -rf gpurun_out/r01g_stats gpurun_out/r01g_fetch gpurun_out/r01g_write gpurun_out/r01g_p2ptrace
