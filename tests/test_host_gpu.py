@@ -175,3 +175,46 @@ def test_native_rccl_exchange_loopback(hip_api):
     assert (e.get_counter("exchange_graph_steps") > 0) == bool(graphs)
     e.comm_destroy()
     e.close(); ref.close()
+
+
+@pytest.mark.parametrize("own", [(41, 120), (1, 80), (81, 160)])
+def test_exchange_mode4_equals_phases_plus_copies(hip_api, own):
+    """vof_step_exchange overlap 4 (fused transport on the edge bands, one send/recv group, fused
+    transport on the other rows) on an interior strip and on the strips next to the left / right wall
+    (one band only), neighbours looped back.  Nothing the second transport launch reads is being
+    received meanwhile, so -- unlike modes 1-3 on a loopback -- the result is deterministic and must
+    equal the phased step followed by hand-made halo copies on every stored row, ghost cells included."""
+    from vof2d import _abi
+    from vof2d.engine import Engine, make_desc, comm_unique_id
+    nx, ny, W = 160, 96, _abi.halo_rows(10)
+    rows = (max(0, own[0] - W), min(nx + 1, own[1] + W))
+    wall_lo, wall_hi = own[0] == 1, own[1] == nx
+    e = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
+    ref = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
+    for x in (e, ref):
+        x.set_init_F(3)
+    e.comm_init(comm_unique_id(hip_api), 0, 1, loopback=True)
+    lo, hi = own[0] - rows[0], own[1] - rows[0]
+
+    def loop(fields):
+        for f in fields:
+            a = ref.get(f, rows)
+            if not wall_lo:
+                a[lo - W:lo] = a[lo:lo + W]
+            if not wall_hi:
+                a[hi + 1:hi + 1 + W] = a[hi - W + 1:hi + 1]
+            ref.set(f, a, rows)
+
+    for n in (1, 1, 3, 2):   # the first step of a communicator is eager (and runs as mode 1), later ones are captured
+        if e.istep == 0:
+            e.step_exchange(1, 0); ref_modes = 1
+        else:
+            e.step_exchange(n, 4); ref_modes = n
+        for _ in range(ref_modes):
+            for ph in (0, 1, 2):
+                ref.step_phase(ph)
+            loop(("p", "u", "v", "F"))
+        for f in ("F", "u", "v", "p"):
+            got, want = e.get(f, rows), ref.get(f, rows)
+            assert np.array_equal(got, want, equal_nan=True), (own, f, int(e.istep), np.argwhere(got != want)[:4])
+    e.comm_destroy(); e.close(); ref.close()
