@@ -599,3 +599,28 @@ def test_virtual_ghosts_are_settled_before_anything_else_looks(hip_api, oracle_a
         # and the run goes on identically (fused steps again, ghosts virtual again)
         a.step(3); b.step(3)
         assert_fields_same(a, b, STATE, ctx="3 more steps after %s" % reader)
+
+
+def test_step_graphs_follow_parity_and_buffer_orientation(hip_api, oracle_api):
+    """The fused transport swaps the F / twin pair once per step, so the captured step graphs are
+    keyed by (sweep-order parity, orientation of the pair).  Resetting istep between steps decouples
+    the two: all four combinations must replay correctly, also with verbs that swap the pair once
+    (a single sweep) in between."""
+    nx, ny = 72, 130
+    a, b = engine(hip_api, nx, ny, "f64", "f32", ic=2), engine(oracle_api, nx, ny, "f64", "f32", ic=2)
+    for e in (a, b):
+        e.step(3)                       # parities 1,0,1; the pair ends swapped
+    assert_fields_same(a, b, STATE, ctx="3 steps")
+    for e in (a, b):
+        e.istep = 10                    # next step has parity 1 again, with the pair the other way round
+        e.step(4)
+    assert_fields_same(a, b, STATE, ctx="after istep = 10")
+    for e in (a, b):
+        e.fct_y_sweep(); e.set_BC()     # one more swap outside the step
+        e.istep = 21
+        e.step(5)
+    assert_fields_same(a, b, STATE, ctx="after a single sweep and istep = 21")
+    for k in range(6):                  # single steps: graph launch, one swap, again
+        for e in (a, b):
+            e.step(1)
+        assert_fields_same(a, b, STATE, ctx="single step %d" % k)
