@@ -787,14 +787,14 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   for (int r = r0; r <= r1; ++r) {
     Row<T, V> F0 = Fn, u1 = un;
     const Row<T, V> v1 = vn;
-    if (edge_cols) {
-      mirror_ghost_cols<T, V>(F0, j0, ny);
-      mirror_ghost_cols<T, V>(u1, j0, ny);
-    }
     if (r < r1) {
       load_F(Fn, r + 1);
       load_u(un, r);
       load_v(vn, r);
+    }
+    if (edge_cols) {   // (after the prefetch has been issued)
+      mirror_ghost_cols<T, V>(F0, j0, ny);
+      mirror_ghost_cols<T, V>(u1, j0, ny);
     }
     // ---- N: normals of row r-1 (:285-306)
     const bool okN = (r - 1) >= ilo && (r - 1) <= ihi;
