@@ -1045,9 +1045,11 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
   for (int64_t s = 0; s < nsteps; ++s) {
     h->istep += 1;
     const int par = (int)(h->istep & 1);
-    // A step that starts with consistent F ghosts runs the lean schedule (one boundary launch, at
-    // the end) from a captured graph; the first step after set_init_F / from_numpy / a single verb
-    // runs the schedule with the reference's intermediate set_BC calls, eagerly.
+    // A step that starts with consistent F ghosts runs the lean schedule from a captured graph
+    // (full domains: k_momentum, 2 x k_jacobi_tb, k_transport and no boundary launch -- virtual
+    // ghosts; strips: the two-kernel transport and one boundary launch at the end); the first step
+    // after set_init_F / from_numpy / a single verb runs the schedule with the reference's
+    // intermediate set_BC calls, eagerly.
     const bool lean = !h->f_ghosts_dirty;
     const bool virt = step_leaves_ghosts_virtual(h);
     if (!virt) settle_ghosts(h);
