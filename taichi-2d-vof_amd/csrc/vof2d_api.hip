@@ -459,15 +459,24 @@ struct L {
            (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
   }
   // update_uv + both sweeps + post_process_f in one pass (k_transport); reads fld[fF], writes fld[fF2]
-  // rows [a, b] (and [a2, b2] if b2 >= a2) of the output; 0, 0: all computable rows
+  static int transport_rows(const vof2d_ctx* h) {
+    return h->fctx_corr_rows > 0 ? h->fctx_corr_rows : chunk_rows(h, h->nty, 4, 16);
+  }
+  static long range_chunks(const RowRanges& rr) {
+    long n = 0;
+    for (int k = 0; k < 3; ++k)
+      if (rr.last[k] >= rr.first[k]) n += (rr.last[k] - rr.first[k] + rr.R[k]) / rr.R[k];
+    return n;
+  }
+  // the rows of rr (all computable rows by default)
   template <bool YFIRST>
-  static void transport(vof2d_ctx* h, int a = 0, int b = 0, int a2 = 1, int b2 = 0, int Rforce = 0) {
-    if (a == 0 && b == 0) { a = h->g.ilo; b = h->g.ihi; }
-    const int R = Rforce > 0 ? Rforce : (h->fctx_corr_rows > 0 ? h->fctx_corr_rows : chunk_rows(h, h->nty, 4, 16));
-    const long chunks = (b - a + R) / R + (b2 >= a2 ? (b2 - a2 + R) / R : 0);
-    launch(h, kTransport, k_transport<T, V, YFIRST>, dim3((unsigned)((chunks * h->nty + 3) / 4)), 0, h->g, C(h),
-           (const T*)F_<T>(h, fF), F_<T>(h, fF2), R, h->nty, (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS),
-           (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, a, b, a2, b2);
+  static void transport(vof2d_ctx* h, const RowRanges* ranges = nullptr) {
+    RowRanges rr;
+    if (ranges) rr = *ranges;
+    else rr = RowRanges{{h->g.ilo, 1, 1}, {h->g.ihi, 0, 0}, {transport_rows(h), 1, 1}};
+    launch(h, kTransport, k_transport<T, V, YFIRST>, dim3((unsigned)((range_chunks(rr) * h->nty + 3) / 4)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fF), F_<T>(h, fF2), h->nty, (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS),
+           (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, rr);
   }
 };
 
@@ -508,31 +517,32 @@ void final_sweep(vof2d_ctx* h, bool along_x, int part) {
   }
 }
 
-// The fused transport (k_transport) on the owned rows of a strip, all at once or in the two parts
-// of TransportPart: both edge bands in ONE launch, then the rest.
+// The fused transport (k_transport) on the owned rows of a strip: all at once (kAllOwned), only the
+// two W-row bands at its interior edges (kEdgeBands: both in ONE launch), or only the rest (kRest).
 template <typename T>
 void transport_part(vof2d_ctx* h, bool y_first, int part) {
   const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
   const int lo = h->d.own_lo > h->g.ilo ? h->d.own_lo : h->g.ilo, hi = h->d.own_hi < h->g.ihi ? h->d.own_hi : h->g.ihi;
   const bool band_lo = !h->g.wall_lo, band_hi = !h->g.wall_hi;
-  // the bands are few rows: short chunks, so that the launch is many short-lived waves (2 x 16 rows
-  // of an 8192-wide strip: 31 us with 16-row chunks, see profiles) instead of a few long ones
-  const int Rband = h->band_rows;
-  auto run = [&](int a, int b, int a2, int b2) {
-    if (b < a && b2 < a2) return;
-    if (b < a) { a = a2; b = b2; a2 = 1; b2 = 0; }
-    const int Rf = part == kEdgeBands ? Rband : 0;
-    if (y_first) L<T>::template transport<true>(h, a, b, a2, b2, Rf); else L<T>::template transport<false>(h, a, b, a2, b2, Rf);
-  };
   const int in_lo = band_lo ? lo + W : lo, in_hi = band_hi ? hi - W : hi;   // strips are >= W rows thick
   const bool split = in_lo <= in_hi && (band_lo || band_hi);
-  if (part == kAllOwned || !(band_lo || band_hi)) { if (part != kEdgeBands) run(lo, hi, 1, 0); return; }
-  if (part == kEdgeBands) {
-    if (!split) { run(lo, hi, 1, 0); return; }   // the bands meet: everything is edge
-    run(band_lo ? lo : 1, band_lo ? in_lo - 1 : 0, band_hi ? in_hi + 1 : 1, band_hi ? hi : 0);
-  } else if (split) {
-    run(in_lo, in_hi, 1, 0);
+  // the bands are few rows: short chunks, so that they are many short-lived waves (2 x 16 rows of an
+  // 8192-wide strip: 31 us with 16-row chunks, 15-18 us with 4-row chunks)
+  const int Rb = h->band_rows, R = L<T>::transport_rows(h);
+  RowRanges rr{{1, 1, 1}, {0, 0, 0}, {Rb, Rb, R}};
+  if (part == kAllOwned || !split) {
+    // one range: a full domain has no bands (everything is "rest"); where the bands meet there is
+    // no rest (everything is "bands")
+    if (part == kRest && (band_lo || band_hi)) return;
+    if (part == kEdgeBands && !(band_lo || band_hi)) return;
+    rr.first[2] = lo; rr.last[2] = hi;
+  } else if (part == kEdgeBands) {
+    if (band_lo) { rr.first[0] = lo; rr.last[0] = in_lo - 1; }
+    if (band_hi) { rr.first[1] = in_hi + 1; rr.last[1] = hi; }
+  } else {
+    rr.first[2] = in_lo; rr.last[2] = in_hi;
   }
+  if (y_first) L<T>::template transport<true>(h, &rr); else L<T>::template transport<false>(h, &rr);
 }
 
 // interior copy src -> dst (only used to keep p in place for odd sweep counts)

@@ -1690,16 +1690,21 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
 // [ilo, ihi] enter the x pipeline unswept (YFIRST), and F' in the ghost columns only ever meets the
 // zero wall velocity v[:,1] = v[:,ny+1] = 0 (x first).
 
+// Up to three row ranges a launch produces, in this order, each cut in chunks of its own length
+// (an empty range has last < first): e.g. the two edge bands of a strip in short chunks.
+struct RowRanges {
+  int first[3], last[3], R[3];
+};
+
 template <typename T, int V, bool YFIRST>
 __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T* __restrict__ F, T* __restrict__ Fn,
-                                                    int R, int nty, const T* __restrict__ us,
+                                                    int nty, const T* __restrict__ us,
                                                     const T* __restrict__ vs, const T* __restrict__ p,
                                                     T* __restrict__ Uo, T* __restrict__ Vo,
-                                                    unsigned long long* __restrict__ courant, int rfirst, int rlast,
-                                                    int rfirst2, int rlast2) {
-  // rows [rfirst, rlast] and (optionally, rlast2 >= rfirst2) [rfirst2, rlast2] are produced -- all
-  // computable rows of a full domain; on a strip the owned rows, or first only their two edge
-  // bands (what the neighbours wait for) and then the rest.  The sweeps' domain stays [ilo, ihi].
+                                                    unsigned long long* __restrict__ courant, RowRanges rr) {
+  // rr: all computable rows of a full domain; on a strip the owned rows -- as one range, or the two
+  // edge bands (what the neighbours wait for) first and then the rest, in one launch or in two.
+  // The sweeps' domain stays [ilo, ihi].
   constexpr int W = 64 * V, STRIDE = W - 8;
   WaveTimer wt_(WT_TRANSPORT);
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1708,10 +1713,15 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
   const int c0 = -3 + tj * STRIDE;
   const int j0 = c0 + lane * V;
   const int ilo = g.ilo, ihi = g.ihi, nx = g.nx, ny = g.ny;
-  const int nch1 = (rlast - rfirst + R) / R;   // chunks of the first range
-  const int lo = ch < nch1 ? rfirst : rfirst2, hi = ch < nch1 ? rlast : rlast2;
-  const int ra = lo + (ch < nch1 ? ch : ch - nch1) * R;
-  if (ra > hi) return;  // wave-uniform
+  int k = 0, cbase = 0;   // range of this chunk (wave-uniform)
+  for (; k < 3; ++k) {
+    const int n = rr.last[k] >= rr.first[k] ? (rr.last[k] - rr.first[k] + rr.R[k]) / rr.R[k] : 0;
+    if (ch < cbase + n) break;
+    cbase += n;
+  }
+  if (k == 3) return;  // padding waves of the last block
+  const int R = rr.R[k], hi = rr.last[k];
+  const int ra = rr.first[k] + (ch - cbase) * R;
   const int rb = ra + R - 1 < hi ? ra + R - 1 : hi;
   const int jlo = c0 + 4 > 1 ? c0 + 4 : 1;
   const int jhi = c0 + W - 5 < ny ? c0 + W - 5 : ny;

@@ -154,7 +154,7 @@ def test_native_rccl_exchange_loopback(hip_api):
     # (between real neighbours they are rewritten with identical values), so rows near the edges
     # depend on timing here.  Deterministic and checked: every halo ends up holding the final
     # owned rows next to it, and rows deeper than one step's dependency cone equal the reference.
-    for mode in (1, 2, 3, 1, 2, 3, 2, 1, 4, 4, 4, 1, 4, 4, 2):   # 4: fused transport, one F / twin swap per step
+    for mode in (1, 2, 3, 1, 2, 3, 2, 1, 4, 4, 4, 1, 4, 4, 2, 4, 3, 4):   # 4: fused transport, one F / twin swap per step
         for f in ("F", "u", "v", "p"):
             ref.set(f, e.get(f, rows), rows)
         ref.istep = e.istep
@@ -177,11 +177,11 @@ def test_native_rccl_exchange_loopback(hip_api):
     e.close(); ref.close()
 
 
-@pytest.mark.parametrize("own", [(41, 120), (1, 80), (81, 160)])
+@pytest.mark.parametrize("own", [(41, 120), (1, 80), (81, 160), (70, 95)])
 def test_exchange_mode4_equals_phases_plus_copies(hip_api, own):
     """vof_step_exchange overlap 4 (fused transport on the edge bands, one send/recv group, fused
-    transport on the other rows) on an interior strip and on the strips next to the left / right wall
-    (one band only), neighbours looped back.  Nothing the second transport launch reads is being
+    transport on the other rows) on an interior strip, on the strips next to the left / right wall (one
+    band only) and on a strip so thin that its bands meet, neighbours looped back.  Nothing the second transport launch reads is being
     received meanwhile, so -- unlike modes 1-3 on a loopback -- the result is deterministic and must
     equal the phased step followed by hand-made halo copies on every stored row, ghost cells included."""
     from vof2d import _abi
@@ -214,7 +214,19 @@ def test_exchange_mode4_equals_phases_plus_copies(hip_api, own):
             for ph in (0, 1, 2):
                 ref.step_phase(ph)
             loop(("p", "u", "v", "F"))
+        # (if an earlier test of this process imported torch, its bundled RCCL 2.26.6 is the copy the
+        # library finds; that one cannot be captured, mode 4 then runs as eager mode 1, whose
+        # transfers overlap kernels that read the halos: only rows deeper than one step's
+        # dependency cone, and the halos' final contents, are deterministic on a loopback)
+        captured = bool(e.comm_info()[1])
         for f in ("F", "u", "v", "p"):
             got, want = e.get(f, rows), ref.get(f, rows)
-            assert np.array_equal(got, want, equal_nan=True), (own, f, int(e.istep), np.argwhere(got != want)[:4])
+            if captured:
+                assert np.array_equal(got, want, equal_nan=True), (own, f, int(e.istep), np.argwhere(got != want)[:4])
+            else:
+                a0, a1 = (lo if wall_lo else lo + W), (hi + 1 if wall_hi else hi + 1 - W)
+                assert np.array_equal(got[a0:a1], want[a0:a1], equal_nan=True), (own, f, int(e.istep))
+        if not captured:   # keep the two engines identical for the next round
+            for f in ("F", "u", "v", "p"):
+                ref.set(f, e.get(f, rows), rows)
     e.comm_destroy(); e.close(); ref.close()
