@@ -1765,7 +1765,18 @@ __global__ void k_selftest_division(uint64_t seed, int64_t n, T* __restrict__ oa
   const T y = (T)1.0 / b;
   oa[id] = a;
   ob[id] = b;
-  oq[id] = dabs<T>(b) < (T)1 ? div_by_const<T, true>(a, b, y) : div_by_const<T, false>(a, b, y);
+  // |b| < 1: the scalar routine with the huge-numerator tier.  |b| >= 1: the V-wide form the fused
+  // Jacobi kernel uses (wave-level branches), fed with this lane's and its neighbour's operands --
+  // the categories alternate by lane, so tiny, ordinary, special and tie numerators meet in one wave.
+  T q = div_by_const<T, true>(a, b, y);
+  {
+    const T a2 = __shfl_xor(a, 1, 64), b2 = __shfl_xor(b, 1, 64), y2 = __shfl_xor(y, 1, 64);
+    const T av[2] = {a, a2}, bv[2] = {b, b2}, yv[2] = {y, y2};
+    T rv[2];
+    div_by_const_v<T, 2, false>(rv, av, bv, yv);
+    if (!(dabs<T>(b) < (T)1)) q = ((id >> 3) & 1) ? rv[0] : div_by_const<T, false>(a, b, y);   // both forms get checked
+  }
+  oq[id] = q;
 }
 }  // namespace
 extern "C" {
