@@ -160,7 +160,8 @@ int vof_interp_velocity(vof2d_handle h, void* dst, size_t nbytes);
 /* settable: sigma (sigma[None], :28-29).  readable: sigma dt dx dy dxi dyi
  * dxi2 dyi2 Lx Ly rho_l rho_g nu_l nu_g gx gy (Python-double values).
  * Schedule knobs (settable, results never change; also as VOF2D_* environment variables at
- * vof_create): jacobi_tb (sweeps fused per launch: 5, 2 or 1), jacobi_tb_rows, jacobi_tb_narrow,
+ * vof_create): jacobi_tb (sweeps fused per launch: 5, 2 or 1), jacobi_tb_rows, jacobi_tb_narrow (one column per
+ * lane in the fused Jacobi kernel: 1 on thin wide strips, 2 on any grid),
  * momentum_rows, fctx_rows, fctx_corr_rows, band_rows, rows_per_wave (rows a wave marches; 0 =
  * heuristic), fuse_momentum, fuse_correct, fuse_transport (update_uv + both sweeps as one kernel on
  * full domains; readable: 1 if in effect), virtual_ghosts (no set_BC launch in steady-state steps). */

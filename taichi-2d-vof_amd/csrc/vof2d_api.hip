@@ -422,7 +422,7 @@ struct L {
     // strip step), so it is opt-in (jacobi_tb_narrow = 1).  On full grids two columns per lane win
     // throughout (4096^2: 89 vs 103 us, 2048^2: 30 vs 35 us).  Square cells, five sweeps, fp64 only.
     if constexpr (sizeof(T) == 8 && TS == 5 && V == 2) {
-      if (sq && R < 32 && ntt >= 48 && h->tb_rows <= 0 && h->tb_narrow != 0) {
+      if (sq && h->tb_rows <= 0 && ((R < 32 && ntt >= 48 && h->tb_narrow != 0) || h->tb_narrow == 2)) {   // 2: on any grid
         int ntt1 = 0;
         const int R1 = jacobi_tb_plan<TS, 1>(h, sq, ntt1);
         jacobi_tb_launch<TS, 1>(h, cc, sq, src, dst, R1, ntt1);
