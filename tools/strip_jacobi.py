@@ -17,7 +17,7 @@ def main():
     from vof2d.engine import Engine, make_desc
     from vof2d.strips import partition, stored_rows
     api = hip_api()
-    own = partition(a.nx, a.n)[a.rank]
+    own = partition(a.nx, a.n)[a.rank if a.n > 1 else 0]
     rows = stored_rows(a.nx, own, _abi.halo_rows(10)) if a.n > 1 else None
     dt = 4e-6 if max(a.nx, a.ny) <= 4096 else 1e-6
     kw = dict(rows=rows, own=own) if a.n > 1 else {}
