@@ -62,6 +62,9 @@ def parse():
                          "kills it and tries the next carrier (default 300 + 0.01 per step; three times that for torch)")
     ap.add_argument("--no-supervisor", action="store_true", help="N > 1: run in this process, no watchdog / fallback")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N > 1 (native exchange): keep equal strips instead of re-cutting them by the measured cost of "
+                         "each rank's rows (strips.balanced_partition)")
     ap.add_argument("--overlap", type=int, default=4, choices=[0, 1, 2, 3, 4],
                     help="N > 1: 0 = one exchange after the step, 1 = each field as soon as it is final, "
                          "2 = 1 + F's edge bands first, 3 = p, u, v together after the first sweep, 4 = fused transport "
@@ -281,9 +284,39 @@ def main():
         from vof2d.strips import StripSolver
         try:
             comm = EnvComm(rank, world, local)
-            with _StdoutToStderr():
-                solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local,
-                                     jacobi_iters=a.jacobi_iters, comm=comm, exchange="native" if world > 1 else "auto", dt=dt)
+            def make_solver(parts=None):
+                with _StdoutToStderr():
+                    return StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local, parts=parts,
+                                       jacobi_iters=a.jacobi_iters, comm=comm, exchange="native" if world > 1 else "auto", dt=dt)
+            solver = make_solver()
+            parts = solver.parts
+            if world > 1 and not a.no_balance:
+                # Strips do not cost the same: rows of gas take the sweeps' zero shortcuts, the liquid and
+                # the interface do not (and GPUs differ a little).  Time each rank's own kernels on the
+                # equal strips (no exchange: the halos go stale, the state is thrown away), re-cut the rows
+                # so that every rank gets the same share of the cost, and start again from the initial
+                # condition.  Results do not depend on the partition.
+                import pickle
+                from vof2d.strips import balanced_partition
+                solver.eng.step(3)
+                solver.eng.sync()
+                t0 = time.perf_counter()
+                solver.eng.step(8)
+                solver.eng.sync()
+                cost = (time.perf_counter() - t0) / 8
+                costs = comm.gather_object(cost)
+                blob = None
+                if rank == 0:
+                    try:
+                        blob = pickle.dumps(balanced_partition(nx, parts, costs, min_rows=solver.halo))
+                    except Exception as exc:      # keep every rank on the same partition whatever happens here
+                        print("[bench] cost balancing failed (%r): equal strips" % (exc,), file=sys.stderr)
+                        blob = pickle.dumps(parts)
+                parts = pickle.loads(comm.broadcast_bytes(blob))
+                solver.barrier()
+                with _StdoutToStderr():
+                    solver.close()
+                solver = make_solver(parts)
             native_ok = True
         except Exception as exc:   # e.g. no loadable RCCL: symmetric on all ranks -> the torch carrier
             print("[bench] native RCCL exchange unavailable (%r); falling back to torch.distributed" % (exc,), file=sys.stderr)
@@ -418,6 +451,7 @@ def main():
                     world, solver.halo, exchange, a.overlap)),
                 "nx": nx, "ny": ny, "dt": dt, "jacobi_iters": a.jacobi_iters,
                 "exchange": exchange, "overlap": a.overlap if dist_path else None,
+                "rows_per_rank": [hi - lo + 1 for lo, hi in solver.parts] if dist_path else None,
                 "exchange_graph": (eng.comm_info()[1] == 1) if exchange == "native" else None,
                 "arrays_per_cell_update": ARRAYS_PER_STEP,
                 "bytes_per_cell_update_algorithmic": ARRAYS_PER_STEP * esz},

@@ -37,6 +37,31 @@ def partition(nx, world):
     return [(bounds[k] + 1, bounds[k + 1]) for k in range(world)]
 
 
+def balanced_partition(nx, parts, costs, min_rows=1):
+    """Re-cut the rows so that every rank gets the same share of the measured cost.
+
+    parts: the partition the measurement was taken with; costs[r]: what rank r's strip cost there
+    (e.g. seconds per step of its kernels).  The cost of a row is taken as uniform within each old
+    strip -- strips differ because their contents do: rows full of gas take the sweeps' zero
+    shortcuts, rows at the interface pay for normals and surface tension -- and the new boundaries
+    are where the cumulative cost reaches k / world of the total.  Every strip keeps >= min_rows rows
+    (the halo depth).  Results do not depend on the partition (no collective on the data path)."""
+    world = len(parts)
+    if world == 1:
+        return list(parts)
+    dens = np.concatenate([np.full(hi - lo + 1, float(c) / (hi - lo + 1)) for (lo, hi), c in zip(parts, costs)])
+    assert len(dens) == nx and np.all(dens > 0)
+    cum = np.concatenate([[0.0], np.cumsum(dens)])
+    cuts = [0]
+    for k in range(1, world):
+        b = int(np.searchsorted(cum, cum[-1] * k / world))      # first row count whose cumulative cost reaches the share
+        b = max(b, cuts[-1] + min_rows)
+        b = min(b, nx - (world - k) * min_rows)
+        cuts.append(b)
+    cuts.append(nx)
+    return [(cuts[k] + 1, cuts[k + 1]) for k in range(world)]
+
+
 def stored_rows(nx, own, halo):
     lo, hi = own
     return max(0, lo - halo), min(nx + 1, hi + halo)
@@ -61,7 +86,7 @@ class StripSolver:
     With an EnvComm and the native exchange the process never imports torch."""
 
     def __init__(self, nx, ny, dtype="f64", ic=1, coord_cast="f32", jacobi_iters=10, rank=0, world=1,
-                 device=None, api=None, dist=None, exchange="auto", comm=None, **consts):
+                 device=None, api=None, dist=None, exchange="auto", comm=None, parts=None, **consts):
         if exchange not in ("auto", "native", "torch"):
             raise ValueError("exchange must be 'auto', 'native' or 'torch'")
         if api is None:
@@ -72,9 +97,14 @@ class StripSolver:
         self.rank, self.world = rank, world
         self.nx, self.ny = nx, ny
         self.halo = _abi.halo_rows(jacobi_iters)
-        parts = partition(nx, world)
+        # parts: the owned rows of every rank (default: equal strips; see balanced_partition)
+        parts = [tuple(int(x) for x in pr) for pr in parts] if parts is not None else partition(nx, world)
+        if len(parts) != world or parts[0][0] != 1 or parts[-1][1] != nx or \
+                any(parts[k][1] + 1 != parts[k + 1][0] for k in range(world - 1)):
+            raise ValueError("parts must be %d contiguous row ranges covering 1..%d" % (world, nx))
         if min(hi - lo + 1 for lo, hi in parts) < self.halo:
-            raise ValueError("strips of %d rows are thinner than the %d-row halo" % (nx // world, self.halo))
+            raise ValueError("strips of %d rows are thinner than the %d-row halo" % (min(hi - lo + 1 for lo, hi in parts), self.halo))
+        self.parts = parts
         self.own = parts[rank]
         self.rows = stored_rows(nx, self.own, self.halo)
         from .comms import EnvComm, TorchComm

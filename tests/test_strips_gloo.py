@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from util import engine, same, diff_report
-from vof2d.strips import partition, stored_rows
+from vof2d.strips import partition, stored_rows, balanced_partition
 from vof2d import halo_rows
 
 
@@ -23,6 +23,40 @@ def test_partition_covers_the_grid():
     assert stored_rows(64, (1, 32), 16) == (0, 48)
     assert stored_rows(64, (33, 64), 16) == (17, 65)
     assert halo_rows(10) == 16
+
+
+def test_balanced_partition_equalises_the_measured_cost():
+    nx, world = 8192, 8
+    eq = partition(nx, world)
+    # ranks 0-2 hold liquid / the interface and are 10 % / 5 % slower than the gas strips
+    costs = [391, 391, 373, 357, 357, 357, 357, 357]
+    parts = balanced_partition(nx, eq, costs, min_rows=16)
+    assert parts[0][0] == 1 and parts[-1][1] == nx
+    assert all(parts[k][1] + 1 == parts[k + 1][0] for k in range(world - 1))
+    dens = np.concatenate([np.full(hi - lo + 1, c / (hi - lo + 1)) for (lo, hi), c in zip(eq, costs)])
+    new_costs = [dens[lo - 1:hi].sum() for lo, hi in parts]
+    assert max(new_costs) < 1.002 * sum(costs) / world < 0.96 * max(costs)
+    assert parts[0][1] - parts[0][0] + 1 < 1024 < parts[-1][1] - parts[-1][0] + 1
+    # equal costs leave the partition alone; a floor on the strip height is kept
+    assert balanced_partition(nx, eq, [1.0] * world) == eq
+    thin = balanced_partition(64, partition(64, 4), [100, 1, 1, 1], min_rows=16)
+    assert [hi - lo + 1 for lo, hi in thin] == [16, 16, 16, 16]
+    assert balanced_partition(100, [(1, 100)], [3.0]) == [(1, 100)]
+
+
+def test_strips_with_an_uneven_partition_equal_single_domain(oracle_api, tmp_path):
+    """Strips of different heights (what bench.py's cost balancing produces) give the same fields."""
+    import torch.multiprocessing as mp
+    import _strip_worker
+    nx, ny, steps, world = 100, 24, 10, 3
+    parts = [(1, 22), (23, 71), (72, 100)]
+    mp.spawn(_strip_worker.run, args=(world, _free_port(), nx, ny, 1, "f64", steps, str(tmp_path), True, parts),
+             nprocs=world, join=True)
+    z = np.load(tmp_path / "strips.npz")
+    ref = engine(oracle_api, nx, ny, "f64", "f32", ic=1)
+    ref.step(steps)
+    for f in ("F", "u", "v", "p"):
+        assert same(z[f], ref.get(f)), diff_report(z[f], ref.get(f), f)
 
 
 def _free_port():
