@@ -290,7 +290,7 @@ def main():
                                        jacobi_iters=a.jacobi_iters, comm=comm, exchange="native" if world > 1 else "auto", dt=dt)
             solver = make_solver()
             parts = solver.parts
-            if world > 1 and not a.no_balance:
+            if (world > 1 or os.environ.get("VOF2D_BENCH_TEST_BALANCE")) and not a.no_balance:   # (env: self-test of this block with one rank)
                 # Strips do not cost the same: rows of gas take the sweeps' zero shortcuts, the liquid and
                 # the interface do not (and GPUs differ a little).  Time each rank's own kernels on the
                 # equal strips (no exchange: the halos go stale, the state is thrown away), re-cut the rows
