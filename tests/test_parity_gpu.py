@@ -640,3 +640,19 @@ def test_300_steps_of_the_fused_schedule(hip_api, oracle_api, nx, ny, ic):
         a.step(st - done); b.step(st - done); done = st
         assert_fields_same(a, b, STATE + SCRATCH, ctx="%dx%d ic%d step %d" % (nx, ny, ic, st))
     assert a.get_counter("courant_violations") == b.get_counter("courant_violations")
+
+
+def test_long_runs_are_deterministic(hip_api):
+    """Two independent handles (one replaying captured graphs, one launching eagerly) stay bit-identical
+    over 1500 steps at 1024 x 768 with surface tension: no race in the fused kernels, in the virtual
+    ghosts or in the F / twin bookkeeping.  (No oracle at this size and length.)"""
+    nx, ny = 1024, 768
+    a = engine(hip_api, nx, ny, "f64", "f32", ic=3)
+    b = engine(hip_api, nx, ny, "f64", "f32", ic=3, flags=VOF_FLAG_NO_GRAPH)
+    for chunk in (1, 499, 1000):
+        a.step(chunk); b.step(chunk)
+        for f in STATE:
+            x, y = a.get(f), b.get(f)
+            assert np.array_equal(x, y, equal_nan=True), (f, int(a.istep), int((x != y).sum()))
+    F = a.get("F")
+    assert np.isfinite(F).all() and F.min() >= 0.0 and F.max() <= 1.0
