@@ -123,14 +123,31 @@ int vof_step_phase(vof2d_handle h, int32_t phase);
 int vof_get_istep(vof2d_handle h, int64_t* istep);
 int vof_set_istep(vof2d_handle h, int64_t istep);
 
-/* Extension (not in the reference): Jacobi sweeps until
- * max|p_new - p| over owned rows <= tol, checked every check_every sweeps,
- * at most max_iters.  *residual is this handle's local value. */
+/* Extension (not in the reference, whose :521-522 runs a fixed 10 sweeps; SURVEY 8f-1, BASELINE
+ * configs[1] "Jacobi Poisson to 1e-6 residual"): rhs once, then Jacobi sweeps (:258-266) until the
+ * residual of the last sweep of a batch is <= tol, checked every check_every sweeps, at most
+ * max_iters sweeps.  The sweeps of a batch run fused (five per launch) and the last launch reduces
+ * the two norms itself.
+ *   VOF_RESID_ABS:  residual = max|p_new - p|                                  over owned rows
+ *   VOF_RESID_REL:  residual = max|p_new - p| / max(max|p_new|, VOF_RESID_TINY)   
+ * A non-finite update (a diverged field) reads as residual = +inf and ends the solve.
+ * *residual is this handle's local value; a multi-GPU driver all-reduces the two norms of
+ * vof_jacobi_sweeps_norms itself (vof2d/strips.py). */
+#define VOF_RESID_ABS 0
+#define VOF_RESID_REL 1
+#define VOF_RESID_TINY 1e-300
+int vof_solve_p(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every, int32_t criterion,
+                int32_t* iters_done, double* residual);
+/* = vof_solve_p(..., VOF_RESID_ABS, ...) */
 int vof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every,
                          int32_t* iters_done, double* residual);
-/* one rhs build + n sweeps + local max|p_new - p| of the last sweep
- * (building block for the distributed residual all-reduce). */
+/* rhs build (if build_rhs) + n sweeps; *max_update = max|p_new - p| and *max_p = max|p_new| of the
+ * last sweep over this handle's owned rows (a NaN entry counts as +inf). */
+int vof_jacobi_sweeps_norms(vof2d_handle h, int32_t n, int32_t build_rhs, double* max_update, double* max_p);
+/* the max_update half of vof_jacobi_sweeps_norms */
 int vof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual);
+/* the residual of a criterion from the two (possibly all-reduced) norms; +inf for a non-finite update */
+double vof_residual_value(double max_update, double max_p, int32_t criterion);
 
 /* ---- fields: F.to_numpy() / F.from_numpy() (2dvof.py:44,46,535,565) ----
  * names: F u v p u_star v_star mx my kappa rho nu rhs */

@@ -162,29 +162,50 @@ int ovof_solve_p_jacobi(vof2d_handle h, int32_t n) {
   for (int k = 0; k < n; ++k) DISPATCH(h, solve_p_jacobi, NULL);
   return VOF_OK;
 }
-/* Extension: n sweeps, *residual = max|p_new - p| over owned rows of the last one. */
-int ovof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual) {
-  if (!h || !residual || n < 1) return VOF_EINVAL;
+double ovof_residual_value(double max_update, double max_p, int32_t criterion) {
+  if (!(max_update < HUGE_VAL)) return HUGE_VAL;   /* inf or NaN: diverged */
+  if (criterion == VOF_RESID_ABS) return max_update;
+  return max_update / (max_p > VOF_RESID_TINY ? max_p : VOF_RESID_TINY);
+}
+/* Extension: n sweeps; max|p_new - p| and max|p_new| over owned rows of the last one. */
+int ovof_jacobi_sweeps_norms(vof2d_handle h, int32_t n, int32_t build_rhs, double* max_update, double* max_p) {
+  if (!h || !max_update || !max_p || n < 1) return VOF_EINVAL;
   /* the extension defines rhs on the CURRENT F (rho = f(F)); the sweeps below recompute the
    * iteration-invariant rhs from the rho array every time, like :239-241 */
   if (build_rhs) ovof_cal_nu_rho(h);
-  for (int k = 0; k < n; ++k) DISPATCH(h, solve_p_jacobi, k == n - 1 ? residual : NULL);
+  double norms[2] = {0.0, 0.0};
+  for (int k = 0; k < n; ++k) DISPATCH(h, solve_p_jacobi, k == n - 1 ? norms : NULL);
+  *max_update = norms[0];
+  *max_p = norms[1];
   return VOF_OK;
 }
-int ovof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every, int32_t* iters_done,
-                          double* residual) {
+int ovof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual) {
+  double pmax;
+  if (!residual) return VOF_EINVAL;
+  return ovof_jacobi_sweeps_norms(h, n, build_rhs, residual, &pmax);
+}
+/* same driver loop as vof_solve_p (include/vof2d.h) */
+int ovof_solve_p(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every, int32_t criterion,
+                 int32_t* iters_done, double* residual) {
   if (!h || !iters_done || !residual || max_iters < 1 || check_every < 1) return VOF_EINVAL;
+  if (criterion != VOF_RESID_ABS && criterion != VOF_RESID_REL) return VOF_EINVAL;
   int done = 0;
   double r = 0.0;
   while (done < max_iters) {
     int n = check_every < max_iters - done ? check_every : max_iters - done;
-    ovof_jacobi_sweeps_residual(h, n, done == 0, &r);
+    double upd = 0.0, pmax = 0.0;
+    ovof_jacobi_sweeps_norms(h, n, done == 0, &upd, &pmax);
     done += n;
-    if (r <= tol) break;
+    r = ovof_residual_value(upd, pmax, criterion);
+    if (r <= tol || !(r < HUGE_VAL)) break;
   }
   *iters_done = done;
   *residual = r;
   return VOF_OK;
+}
+int ovof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every, int32_t* iters_done,
+                          double* residual) {
+  return ovof_solve_p(h, tol, max_iters, check_every, VOF_RESID_ABS, iters_done, residual);
 }
 int ovof_update_uv(vof2d_handle h) { if (!h) return VOF_EINVAL; DISPATCH(h, update_uv); return VOF_OK; }
 int ovof_fct_x_sweep(vof2d_handle h) { if (!h) return VOF_EINVAL; DISPATCH(h, fct_x_sweep); return VOF_OK; }

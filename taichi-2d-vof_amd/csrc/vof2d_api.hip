@@ -136,7 +136,7 @@ struct vof2d_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int device = 0;
-  unsigned long long* d_courant = nullptr;  // device counters: [0] courant, [1] residual bits
+  unsigned long long* d_courant = nullptr;  // device counters: [0] courant, [1] max|p_new - p| bits, [2] max|p_new| bits (residual solve)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t istep = 0;
   int rows_override = 0;
@@ -396,17 +396,38 @@ struct L {
     constexpr int Wt = 64 * VV;
     const int Ht = ((TS - 1 + (sq ? 1 : 0) + VV - 1) / VV) * VV, ST = Wt - 2 * Ht;  // must match the kernel
     ntt = (h->g.ny + ST - 1) / ST;
-    const long cap = sq ? resident_waves(h, k_jacobi_tb<T, VV, TS, true>) : resident_waves(h, k_jacobi_tb<T, VV, TS, false>);
+    const long cap = sq ? resident_waves(h, k_jacobi_tb<T, VV, TS, true, false>) : resident_waves(h, k_jacobi_tb<T, VV, TS, false, false>);
     return h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
   }
   template <int TS, int VV>
   static void jacobi_tb_launch(vof2d_ctx* h, const Consts<T>& cc, bool sq, int src, int dst, int R, int ntt) {
+    unsigned long long* none = nullptr;
     if (sq)
-      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none);
     else
-      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt);
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, false, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none);
+  }
+  // TS sweeps src -> dst, the last of which also reduces max|p_new - p| and max|p_new| over the owned
+  // rows into d_courant[1..2] (the residual-terminated solve): same values as
+  // jacobi_tb<TS>, same launch plan (the RESID instantiation needs a few registers more, so its
+  // own occupancy decides the chunk length)
+  template <int TS>
+  static void jacobi_tb_resid(vof2d_ctx* h, int src, int dst) {
+    const Consts<T> cc = C(h);
+    const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;
+    constexpr int Wt = 64 * V;
+    const int Ht = ((TS - 1 + (sq ? 1 : 0) + V - 1) / V) * V, ST = Wt - 2 * Ht;
+    const int ntt = (h->g.ny + ST - 1) / ST;
+    const long cap = sq ? resident_waves(h, k_jacobi_tb<T, V, TS, true, true>) : resident_waves(h, k_jacobi_tb<T, V, TS, false, true>);
+    const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
+    if (sq)
+      launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, true, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1);
+    else
+      launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, false, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1);
   }
   template <int TS>
   static void jacobi_tb(vof2d_ctx* h, int src, int dst) {
@@ -571,15 +592,20 @@ void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
   int cur = fP, oth = fPT;
   auto flip = [&]() { int t = cur; cur = oth; oth = t; };
   int left = n;
-  if (resid_last) left -= 1;  // the last sweep carries the max|p_new - p| reduction
   const int tb = h->tb;
+  // the last launch carries the norm reductions of its last sweep: a fused launch where the sweep
+  // count and the handle's fusion depth allow one, else the single-sweep kernel
+  const int last = !resid_last ? 0 : ((tb >= 5 && n >= 5) ? 5 : ((tb >= 2 && n >= 2) ? 2 : 1));
+  left -= last;
   while (left > 0) {
     if (tb >= 5 && left >= 5) { L<T>::template jacobi_tb<5>(h, cur, oth); left -= 5; }
     else if (tb >= 2 && left >= 2) { L<T>::template jacobi_tb<2>(h, cur, oth); left -= 2; }
     else { L<T>::template jacobi<false>(h, cur, oth); left -= 1; }
     flip();
   }
-  if (resid_last) { L<T>::template jacobi<true>(h, cur, oth); flip(); }
+  if (last == 5) { L<T>::template jacobi_tb_resid<5>(h, cur, oth); flip(); }
+  else if (last == 2) { L<T>::template jacobi_tb_resid<2>(h, cur, oth); flip(); }
+  else if (last == 1) { L<T>::template jacobi<true>(h, cur, oth); flip(); }
   if (cur != fP) copy_interior<T>(h, fPT, fP);
 }
 
@@ -742,11 +768,14 @@ struct Rccl {
   int version = 0;
   char why[256] = "";
 };
+Rccl* rccl_bind(Rccl& r);
 Rccl* rccl() {
+  // C++11 magic static: the binding happens once, also when two handles are created on two threads
   static Rccl r;
-  static bool tried = false;
-  if (tried) return r.dl ? &r : nullptr;
-  tried = true;
+  static Rccl* const bound = rccl_bind(r);
+  return bound;
+}
+Rccl* rccl_bind(Rccl& r) {
   const char* cands[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   const char* forced = getenv("VOF2D_RCCL");
   void* dl = (forced && *forced) ? dlopen(forced, RTLD_NOW | RTLD_LOCAL)
@@ -816,21 +845,30 @@ int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1
   HIPCHK(h, hipStreamWaitEvent(h->cstream, ready, 0));
   static const int ids[4] = {fF, fU, fV, fP};
   NCCLCHK(h, r->GroupStart());
+  // Inside the group no early return: a failing send / recv must still be followed by GroupEnd, or
+  // the next (eager) exchange would nest inside the group left open and never be issued.
+  int first_err = 0;
+  const char* what = "";
+  auto note = [&](int rc, const char* call) { if (rc != 0 && first_err == 0) { first_err = rc; what = call; } };
   for (int k = 0; k < 4; ++k) {
     if (!(mask & (1u << k))) continue;
     // between the two transport phases the new F still lives in the twin buffer
     char* base = reinterpret_cast<char*>(h->fld[(k == 0 && f_in_twin) ? fF2 : ids[k]]);
     auto row = [&](int g) { return base + (size_t)(g - h->d.row_lo) * row_bytes; };
     if (h->peer_lo >= 0) {
-      NCCLCHK(h, r->Send(row(h->d.own_lo), bytes, /*ncclInt8*/ 0, h->peer_lo, h->comm, h->cstream));
-      NCCLCHK(h, r->Recv(row(h->d.own_lo - W), bytes, 0, h->peer_lo, h->comm, h->cstream));
+      note(r->Send(row(h->d.own_lo), bytes, /*ncclInt8*/ 0, h->peer_lo, h->comm, h->cstream), "ncclSend(lo)");
+      note(r->Recv(row(h->d.own_lo - W), bytes, 0, h->peer_lo, h->comm, h->cstream), "ncclRecv(lo)");
     }
     if (h->peer_hi >= 0) {
-      NCCLCHK(h, r->Send(row(h->d.own_hi - W + 1), bytes, 0, h->peer_hi, h->comm, h->cstream));
-      NCCLCHK(h, r->Recv(row(h->d.own_hi + 1), bytes, 0, h->peer_hi, h->comm, h->cstream));
+      note(r->Send(row(h->d.own_hi - W + 1), bytes, 0, h->peer_hi, h->comm, h->cstream), "ncclSend(hi)");
+      note(r->Recv(row(h->d.own_hi + 1), bytes, 0, h->peer_hi, h->comm, h->cstream), "ncclRecv(hi)");
     }
   }
-  NCCLCHK(h, r->GroupEnd());
+  note(r->GroupEnd(), "ncclGroupEnd");
+  if (first_err != 0) {
+    snprintf(h->err, sizeof(h->err), "halo exchange: %s -> %s", what, r->GetErrorString(first_err));
+    return VOF_EHIP;
+  }
   return VOF_OK;
 }
 // the compute stream waits for every exchange posted so far
@@ -922,8 +960,8 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
     if (hipMemsetAsync(h->arena, 0, bytes, h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     for (int k = 0; k < NFIELDS; ++k) h->fld[k] = h->arena + (size_t)k * h->field_elems * h->esz;
     h->f_home = h->fld[fF];
-    if (hipMalloc(reinterpret_cast<void**>(&h->d_courant), 2 * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
-    if (hipMemsetAsync(h->d_courant, 0, 2 * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_courant), 4 * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
+    if (hipMemsetAsync(h->d_courant, 0, 4 * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
   } while (0);
@@ -1165,42 +1203,58 @@ int vof_set_istep(vof2d_handle h, int64_t istep) {
   return VOF_OK;
 }
 
-int vof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual) {
-  if (!h || !residual) return VOF_EINVAL;
+double vof_residual_value(double max_update, double max_p, int32_t criterion) {
+  if (!(max_update < HUGE_VAL)) return HUGE_VAL;   /* inf or NaN: diverged */
+  if (criterion == VOF_RESID_ABS) return max_update;
+  return max_update / (max_p > VOF_RESID_TINY ? max_p : VOF_RESID_TINY);
+}
+int vof_jacobi_sweeps_norms(vof2d_handle h, int32_t n, int32_t build_rhs, double* max_update, double* max_p) {
+  if (!h || !max_update || !max_p) return VOF_EINVAL;
   if (n < 1) return fail(h, VOF_EINVAL, "n must be >= 1");
   settle_ghosts(h);
-  HIPCHK(h, hipMemsetAsync(h->d_courant + 1, 0, sizeof(unsigned long long), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_courant + 1, 0, 2 * sizeof(unsigned long long), h->stream));
   if (build_rhs) DISPATCH_T(h, L<double>::rhs<false>(h), L<float>::rhs<false>(h));
   DISPATCH_T(h, jacobi_n<double>(h, n, true), jacobi_n<float>(h, n, true));
   int rc = ensure_ok(h);
   if (rc) return rc;
-  unsigned long long bits = 0;
-  HIPCHK(h, hipMemcpyAsync(&bits, h->d_courant + 1, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+  unsigned long long bits[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(bits, h->d_courant + 1, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  double r;
-  memcpy(&r, &bits, sizeof(r));
-  *residual = r;
+  memcpy(max_update, &bits[0], sizeof(double));
+  memcpy(max_p, &bits[1], sizeof(double));
   return VOF_OK;
 }
+int vof_jacobi_sweeps_residual(vof2d_handle h, int32_t n, int32_t build_rhs, double* residual) {
+  double pmax = 0.0;
+  if (!residual) return VOF_EINVAL;
+  return vof_jacobi_sweeps_norms(h, n, build_rhs, residual, &pmax);
+}
 
-int vof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every, int32_t* iters_done,
-                         double* residual) {
+int vof_solve_p(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every, int32_t criterion,
+                int32_t* iters_done, double* residual) {
   if (!h || !iters_done || !residual) return VOF_EINVAL;
   if (max_iters < 1 || check_every < 1) return fail(h, VOF_EINVAL, "max_iters and check_every must be >= 1");
+  if (criterion != VOF_RESID_ABS && criterion != VOF_RESID_REL) return fail(h, VOF_EINVAL, "criterion must be VOF_RESID_ABS or VOF_RESID_REL");
   int done = 0;
   double r = 0.0;
   bool first = true;
   while (done < max_iters) {
-    int n = check_every < max_iters - done ? check_every : max_iters - done;
-    int rc = vof_jacobi_sweeps_residual(h, n, first ? 1 : 0, &r);
+    const int n = check_every < max_iters - done ? check_every : max_iters - done;
+    double upd = 0.0, pmax = 0.0;
+    int rc = vof_jacobi_sweeps_norms(h, n, first ? 1 : 0, &upd, &pmax);
     if (rc) return rc;
     first = false;
     done += n;
-    if (r <= tol) break;
+    r = vof_residual_value(upd, pmax, criterion);
+    if (r <= tol || !(r < HUGE_VAL)) break;   // converged, or diverged (a non-finite update reads +inf)
   }
   *iters_done = done;
   *residual = r;
   return VOF_OK;
+}
+int vof_solve_p_residual(vof2d_handle h, double tol, int32_t max_iters, int32_t check_every, int32_t* iters_done,
+                         double* residual) {
+  return vof_solve_p(h, tol, max_iters, check_every, VOF_RESID_ABS, iters_done, residual);
 }
 
 int vof_get_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, void* dst, size_t nbytes) {
@@ -1687,6 +1741,16 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
           memcpy(h->fld, keep, sizeof(keep));
           h->gxchg[par][overlap][ori] = nullptr;
           h->xchg_graph = 0;
+          // a capture that failed after the fork may leave the communication stream inside the
+          // invalidated capture: the eager launches below need a working one
+          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(h->cstream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            (void)hipStreamDestroy(h->cstream);
+            h->cstream = nullptr;
+            if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess)
+              return fail(h, VOF_EHIP, "cannot recreate the communication stream after a failed capture");
+          }
           if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] exchange graph capture failed (%s / %s): eager\n", hipGetErrorString(e), h->err);
         }
       }

@@ -949,11 +949,36 @@ __global__ __launch_bounds__(256) void k_rhs(Geom g, Consts<T> c, const T* __res
   }
 }
 
+// ------------------------------------------------------------------ norms of a sweep (extension)
+// max|p_new - p| and max|p_new| over the cells a wave stores: lane maxima -> wave maximum by
+// __shfl_down -> one atomicMax per wave and norm on the bit pattern (non-negative doubles order like
+// their bit patterns; +inf is the largest).  A NaN update counts as +inf, so a diverged field can
+// never read as converged.
+template <typename T>
+__device__ __forceinline__ void norm_acc(T& upd, T& pmx, T pn, T po) {
+  const T d = dabs<T>(pn - po), a = dabs<T>(pn);
+  upd = d != d ? DivLimits<T>::inf : vmax(upd, d);
+  pmx = a != a ? DivLimits<T>::inf : vmax(pmx, a);
+}
+template <typename T>
+__device__ __forceinline__ void norm_publish(T upd, T pmx, unsigned long long* __restrict__ bits) {
+  double r0 = (double)upd, r1 = (double)pmx;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    r0 = vmax(r0, __shfl_down(r0, s, 64));
+    r1 = vmax(r1, __shfl_down(r1, s, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (r0 > 0.0) atomicMax(bits, (unsigned long long)__double_as_longlong(r0));
+    if (r1 > 0.0) atomicMax(bits + 1, (unsigned long long)__double_as_longlong(r1));
+  }
+}
+
 // ------------------------------------------------------------------ Jacobi
 // 2dvof.py:258-266: one sweep p -> pn (ping-pong replaces the copy-back loop).
 // North-star kernel: 3 arrays * sizeof(T) per cell of HBM traffic.  D rows of
 // p and rhs are prefetched into registers ahead of use.  RESID additionally
-// reduces max|pn - p| over owned rows (wave shuffle -> one atomic per wave);
+// reduces max|pn - p| and max|pn| over owned rows (norm_acc / norm_publish above);
 // not part of the reference (extension).
 template <typename T, int V, int D, bool RESID>
 __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __restrict__ p,
@@ -986,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
       load_s<T, V>(qb[d], rhs + o + (int64_t)d * pitch);
     }
   }
-  T res = (T)0;
+  T res = (T)0, pmx = (T)0;
   for (int i0 = ra; i0 <= rb; i0 += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -1013,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
           out[q] = div_by_const<T>(num, apI[q], yI[q]);
         }
         if (RESID) {
-          if (i >= g.own_lo && i <= g.own_hi && j0 + q <= ny) res = vmax(res, dabs<T>(out[q] - cur.c[q]));
+          if (i >= g.own_lo && i <= g.own_hi && j0 + q <= ny) norm_acc<T>(res, pmx, out[q], cur.c[q]);
         }
       }
       store_s<T, V>(pn + o, out, j0, 1, ny);
@@ -1023,12 +1048,7 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
       o += pitch;
     }
   }
-  if (RESID) {
-    double r = (double)res;
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) r = vmax(r, __shfl_down(r, s, 64));
-    if ((threadIdx.x & 63) == 0 && r > 0.0) atomicMax(resid_bits, (unsigned long long)__double_as_longlong(r));
-  }
+  if (RESID) norm_publish<T>(res, pmx, resid_bits);
 }
 
 // ------------------------------------------------------------------ Jacobi, TS sweeps per launch
@@ -1044,10 +1064,14 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
 // Register rotation: stage s keeps rows i-1, i, i+1 of its input in a ring of three row buffers
 // whose roles advance by one per iteration, and the rhs rows in a ring of six; the row loop is
 // unrolled by 6 with compile-time ring positions, so no value is ever moved between registers.
-template <typename T, int V, int TS, bool SQ>
+// RESID (extension): the LAST of the TS sweeps also reduces max|p_TS - p_(TS-1)| and
+// max|p_TS| over the owned cells the tile stores, so the residual-terminated solve keeps the TS-sweep
+// fusion.  p_(TS-1) of a row is the previous stage's output one iteration earlier (kept in V extra
+// registers when SQ, where the ring holds products rather than values).
+template <typename T, int V, int TS, bool SQ, bool RESID = false>
 __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
                                                     const T* __restrict__ rhs, T* __restrict__ pn, int R,
-                                                    int ntt) {
+                                                    int ntt, unsigned long long* __restrict__ norm_bits = nullptr) {
   // SQ (dxi2 == dyi2 bitwise, i.e. square cells): the stencil has ONE off-diagonal coefficient, so
   // the product coef * p[i,j] is the same number in the equations of all four neighbours of (i,j).
   // Stages 2.. then receive products instead of values -- 1 multiply per cell-sweep instead of 4
@@ -1107,6 +1131,11 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
   for (int k = 0; k < 6; ++k)
 #pragma unroll
     for (int q = 0; q < V; ++q) rq[k][q] = (T)0;
+
+  T pv[V], pv_new[V];        // RESID && SQ: values of sweep TS-1, row i (pv) / row i+1 (pv_new) of the last stage
+  T upd = (T)0, pmx = (T)0;  // RESID: lane maxima of |p_TS - p_(TS-1)| and |p_TS|
+#pragma unroll
+  for (int q = 0; q < V; ++q) pv[q] = pv_new[q] = (T)0;
 
   const int t0 = ra - TS + 2, t1 = rb + TS;
   // phase 0 at t = t0: rows t0-2, t0-1, t0 of p in ring[0][0..2]; rhs row t0-1 in rq slot 0
@@ -1182,6 +1211,17 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
       } else {
         div_by_const_v<T, V>(carry, num, apI, yI);
       }
+      if constexpr (RESID) {
+        if (SQ && s == TS - 1) {
+#pragma unroll
+          for (int q = 0; q < V; ++q) pv_new[q] = carry[q];
+        }
+        if (s == TS && i >= ra && i <= rb && i >= g.own_lo && i <= g.own_hi) {
+#pragma unroll
+          for (int q = 0; q < V; ++q)
+            if (j0 + q >= jlo && j0 + q <= jhi) norm_acc<T>(upd, pmx, carry[q], SQ ? pv[q] : ring[TS - 1][kC][q]);
+        }
+      }
       if (s == 1 && t < t1) {
         // ring[0][kM] (row t-2) is dead now: prefetch row t+1 into it; rhs row t into the free slot
         const T* qn = rowptr(p, t + 1);
@@ -1195,6 +1235,10 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
     }
     const int io = t - TS;
     if (io >= ra && io <= rb) store_s<T, V>(pn + at(g, io, j0), carry, j0, jlo, jhi);
+    if constexpr (RESID && SQ) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) pv[q] = pv_new[q];
+    }
   };
 
   for (int t = t0; t <= t1; t += 6) {
@@ -1210,6 +1254,7 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
     if (t + 5 > t1) break;
     sub(IC<5>{}, t + 5);
   }
+  if constexpr (RESID) norm_publish<T>(upd, pmx, norm_bits);
 }
 
 // ------------------------------------------------------------------ corrector

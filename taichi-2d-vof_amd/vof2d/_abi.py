@@ -13,6 +13,7 @@ VOF_OK, VOF_EINVAL, VOF_EHIP, VOF_ENOMEM, VOF_ESTATE = 0, -1, -2, -3, -4
 VOF_FLAG_NO_GRAPH = 1
 VOF_COMM_ID_BYTES, VOF_COMM_LOOPBACK = 128, 1
 VOF_XCHG_F, VOF_XCHG_U, VOF_XCHG_V, VOF_XCHG_P = 1, 2, 4, 8
+VOF_RESID_ABS, VOF_RESID_REL, VOF_RESID_TINY = 0, 1, 1e-300
 
 ERRNAMES = {VOF_EINVAL: "VOF_EINVAL", VOF_EHIP: "VOF_EHIP", VOF_ENOMEM: "VOF_ENOMEM",
             VOF_ESTATE: "VOF_ESTATE"}
@@ -69,6 +70,9 @@ SIGNATURES = {
     "set_istep": (C.c_int, [H, _i64]),
     "solve_p_residual": (C.c_int, [H, _dbl, _i32, _i32, C.POINTER(_i32), C.POINTER(_dbl)]),
     "jacobi_sweeps_residual": (C.c_int, [H, _i32, _i32, C.POINTER(_dbl)]),
+    "jacobi_sweeps_norms": (C.c_int, [H, _i32, _i32, C.POINTER(_dbl), C.POINTER(_dbl)]),
+    "residual_value": (_dbl, [_dbl, _dbl, _i32]),
+    "solve_p": (C.c_int, [H, _dbl, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_dbl)]),
     "get_field": (C.c_int, [H, _str, C.c_void_p, C.c_size_t]),
     "set_field": (C.c_int, [H, _str, C.c_void_p, C.c_size_t]),
     "get_rows": (C.c_int, [H, _str, _i32, _i32, C.c_void_p, C.c_size_t]),

@@ -148,6 +148,22 @@ class Engine:
                                            C.byref(it), C.byref(res)), "solve_p_residual")
         return it.value, res.value
 
+    def solve_p(self, tol, max_iters, check_every=100, criterion="rel"):
+        """vof_solve_p: sweeps until the residual (\"abs\": max|p_new - p|; \"rel\": that over
+        max(max|p_new|, tiny)) is <= tol; returns (sweeps done, residual)."""
+        crit = {"abs": _abi.VOF_RESID_ABS, "rel": _abi.VOF_RESID_REL}[criterion]
+        it, res = C.c_int32(), C.c_double()
+        self._ck(self.api.solve_p(self._h, float(tol), int(max_iters), int(check_every), crit,
+                                  C.byref(it), C.byref(res)), "solve_p")
+        return it.value, res.value
+
+    def jacobi_sweeps_norms(self, n, build_rhs=True):
+        """(max|p_new - p|, max|p_new|) of the last of n sweeps over the owned rows."""
+        upd, pm = C.c_double(), C.c_double()
+        self._ck(self.api.jacobi_sweeps_norms(self._h, int(n), 1 if build_rhs else 0, C.byref(upd), C.byref(pm)),
+                 "jacobi_sweeps_norms")
+        return upd.value, pm.value
+
     def jacobi_sweeps_residual(self, n, build_rhs=True):
         res = C.c_double()
         self._ck(self.api.jacobi_sweeps_residual(self._h, int(n), 1 if build_rhs else 0, C.byref(res)),

@@ -270,24 +270,38 @@ class StripSolver:
                     for w in works:
                         w.wait()
 
-    def solve_p_residual(self, tol, max_iters, check_every=10):
-        """Extension: Jacobi until the global max|p_new - p| <= tol (all-reduce MAX over ranks).
-        Sweeps between checks use 1-row halos refreshed by `exchange` of p only when world > 1."""
+    def solve_p(self, tol, max_iters, check_every=10, criterion="abs"):
+        """Extension: Jacobi until the GLOBAL residual <= tol -- "abs": max|p_new - p|, "rel": that
+        over max(max|p_new|, tiny) -- both norms all-reduced (MAX) over the ranks.  With strips the
+        sweeps between two halo refreshes of p are limited by the halo depth (jacobi_iters rows of
+        it serve the sweeps), so a check covers at most that many sweeps.  Same sweep counts and
+        the same rule as vof_solve_p on a single domain: n = min(check_every, max_iters - done)."""
+        crit = {"abs": _abi.VOF_RESID_ABS, "rel": _abi.VOF_RESID_REL}[criterion]
+        depth = self.halo - 6           # sweeps the deep halo of p covers between two exchanges
         done, res = 0, float("inf")
         first = True
         with self._ctx():
             while done < max_iters:
-                n = min(check_every, max_iters - done, self.halo - 6 if self.world > 1 else check_every)
-                n = max(n - (n & 1), 2)
-                res = self.eng.jacobi_sweeps_residual(n, build_rhs=first)
-                first = False
+                n = min(check_every, max_iters - done)
+                left = n
+                while left > 0:             # (world == 1: one batch)
+                    k = left if self.world == 1 else min(left, depth)
+                    upd, pmax = self.eng.jacobi_sweeps_norms(k, build_rhs=first)
+                    first = False
+                    left -= k
+                    if self.world > 1:
+                        self.exchange(("p",))
                 done += n
                 if self.world > 1:
-                    res = self.comm.allreduce_max(res, self.eng)
-                    self.exchange(("p",))
-                if res <= tol:
+                    upd = self.comm.allreduce_max(upd, self.eng)
+                    pmax = self.comm.allreduce_max(pmax, self.eng)
+                res = self.api.residual_value(upd, pmax, crit)
+                if res <= tol or not res < float("inf"):
                     break
         return done, res
+
+    def solve_p_residual(self, tol, max_iters, check_every=10):
+        return self.solve_p(tol, max_iters, check_every, "abs")
 
     def sync(self):
         self.eng.sync()

@@ -1,0 +1,337 @@
+"""Golden vectors produced by EXECUTING the reference's own source text.
+
+BUILD CONTAINER ONLY (needs /root/reference; listed in .gpurunignore, only the
+``ref_*.npz`` files it writes travel to the GPU box).
+
+    python tests/golden/make_ref_golden.py --ic 1 --steps 12 [-s]
+
+What it does: runs ``/root/reference/2dvof.py`` unmodified (``runpy.run_path``,
+``sys.argv = ['2dvof.py', '-ic', N]``) with a pure-Python stand-in for the one
+module the image lacks, ``taichi`` (taichi==1.4.1, requirements.txt:3, no wheel
+and no network here).  The kernels' arithmetic is the reference's text,
+interpreted statement by statement by CPython -- not a restatement:
+
+  * ``@ti.kernel`` / ``@ti.func``      -> the function itself (see ``_scoped``),
+  * ``ti.field``                       -> a zero-initialised NumPy array behind
+                                          ``[]``, ``to_numpy``, ``from_numpy``,
+  * ``ti.ndrange / ti.grouped``        -> ``itertools.product`` (sequential),
+  * ``ti.max / min / sqrt / abs``      -> Python's, on IEEE doubles,
+  * ``ti.GUI``                         -> headless; ``running`` turns False after
+                                          ``--steps`` iterations of the reference's
+                                          own ``while gui.running`` loop (:505).
+
+Every field value is an IEEE double (``np.float64`` scalars: the reference with
+only ``default_fp`` changed to f64, which is what BASELINE's fp64 configs are;
+the float32 cast of the coordinates, :43-46, is the reference's and is kept).
+In double precision the result does not depend on Taichi's static typing (every
+int -> float conversion is exact, every Python-scope constant expression is a
+double either way); in fp32 it would (``ap`` at :262, the cell coordinates at
+:105-106 mix ints, constants and field values), so no fp32 vectors are made.
+
+What this pins: the oracle's and the HIP kernels' reading of 2dvof.py:102-455,
+:505-528 -- operation order, switches, loop ranges, zero ghosts, BC order, the
+step-parity rule.  What it does NOT pin: Taichi's code generation
+(``fast_math=True`` may contract / reassociate) and its parallel
+execution -- the stand-in runs each loop sequentially.  That is value-identical
+here because no loop of the hot path reads what another iteration of the same
+loop writes, except the face fluxes ``ax`` / ``ay`` that two iterations store
+with bit-identical expressions.
+
+One deviation from plain CPython, needed to run the text at all:
+``cal_nu_rho`` (:200-201) assigns a local ``F`` from the global field ``F``
+(``F = var(0.0, 1.0, F[I])``).  Taichi resolves the right-hand side before the
+local exists; CPython raises UnboundLocalError.  ``_scoped`` renames such
+locals (``F`` -> ``F__local`` after the assignment, inside the enclosing block)
+and changes nothing else.
+"""
+import argparse
+import ast
+import hashlib
+import inspect
+import itertools
+import math
+import os
+import runpy
+import sys
+import tempfile
+import textwrap
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+STATE = ("F", "u", "v", "p")
+ALL_FIELDS = ("F", "Ftd", "ax", "ay", "cx", "cy", "rp", "rm", "u", "v", "u_star", "v_star", "p", "pt",
+              "rho", "nu", "mx", "my", "kappa")
+
+
+# ----------------------------------------------------------------------------------------------
+# the stand-in module
+class Field:
+    """ti.field(float, shape): dense, zero-initialised, row-major."""
+
+    def __init__(self, dtype=float, shape=()):
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        self.a = np.zeros(shape, dtype=np.float64 if dtype is float else dtype)
+
+    def __getitem__(self, idx):
+        if idx is None:                       # sigma[None]
+            return self.a[()]
+        return self.a[idx]
+
+    def __setitem__(self, idx, val):
+        if idx is None:
+            self.a[()] = val
+        else:
+            self.a[idx] = val
+
+    def __iter__(self):                       # ``for i, j in F`` (:453)
+        return iter(itertools.product(*(range(n) for n in self.a.shape)))
+
+    @property
+    def shape(self):
+        return self.a.shape
+
+    def to_numpy(self):
+        return self.a.copy()
+
+    def from_numpy(self, arr):
+        assert arr.shape == self.a.shape
+        self.a[...] = arr                     # float32 coordinates widen exactly (:44, :46)
+
+
+class IVec(tuple):
+    """Index vector of ti.grouped: supports ``I // r`` (:461)."""
+
+    def __floordiv__(self, r):
+        return IVec(k // r for k in self)
+
+
+class Vector(list):
+    @staticmethod
+    def field(n, dtype=float, shape=()):
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        return Field(dtype, shape + (n,))
+
+
+def ndrange(*dims):
+    rs = [range(*d) if isinstance(d, tuple) else range(d) for d in dims]
+    if len(rs) == 1:
+        return rs[0]
+    return itertools.product(*rs)
+
+
+def grouped(f):
+    return (IVec(t) for t in itertools.product(*(range(n) for n in f.shape)))
+
+
+class _Scoper(ast.NodeTransformer):
+    """See the module docstring: locals that shadow a module global are renamed from the
+    assignment on, block-scoped like Taichi's kernel variables."""
+
+    def __init__(self, glob):
+        self.glob = glob
+        self.map = {}
+
+    def visit_Name(self, node):
+        if isinstance(node.ctx, ast.Load) and node.id in self.map:
+            return ast.copy_location(ast.Name(self.map[node.id], ast.Load()), node)
+        return node
+
+    def _block(self, stmts):
+        saved = dict(self.map)
+        out = [self.visit(s) for s in stmts]
+        self.map = saved
+        return out
+
+    def visit_FunctionDef(self, node):
+        node.body = self._block(node.body)
+        return node
+
+    def visit_For(self, node):
+        node.iter = self.visit(node.iter)
+        node.body = self._block(node.body)
+        return node
+
+    def visit_If(self, node):
+        node.test = self.visit(node.test)
+        node.body = self._block(node.body)
+        node.orelse = self._block(node.orelse)
+        return node
+
+    def visit_Assign(self, node):
+        node.value = self.visit(node.value)   # right-hand side first, with the names as they were
+        for t in node.targets:
+            if isinstance(t, ast.Name) and t.id in self.glob and isinstance(self.glob[t.id], Field):
+                self.map[t.id] = t.id + "__local"
+                t.id = t.id + "__local"
+            else:
+                self.visit(t)
+        return node
+
+
+def _scoped(fn):
+    src = textwrap.dedent(inspect.getsource(fn))
+    tree = ast.parse(src)
+    fdef = tree.body[0]
+    fdef.decorator_list = []
+    sc = _Scoper(fn.__globals__)
+    sc.visit(fdef)
+    ast.fix_missing_locations(tree)
+    ast.increment_lineno(tree, fn.__code__.co_firstlineno - 1)
+    ns = {}
+    exec(compile(tree, fn.__code__.co_filename, "exec"), fn.__globals__, ns)
+    return ns[fn.__name__]
+
+
+class GUI:
+    RELEASE, SPACE = "release", " "
+    hook = None                               # called at the top of every iteration of :505
+    limit = 0
+
+    def __init__(self, *a, **k):
+        self._reads = 0
+        self.shown = 0
+
+    @property
+    def running(self):                        # read once per iteration by ``while gui.running``
+        self._reads += 1
+        return self._reads <= GUI.limit
+
+    @running.setter
+    def running(self, v):
+        pass
+
+    def get_events(self, *a):
+        if GUI.hook:
+            GUI.hook()
+        return []
+
+    def set_image(self, img):
+        self.image = np.asarray(img)
+
+    def show(self, *a):
+        self.shown += 1
+
+    def lines(self, *a, **k):
+        pass
+
+    def triangles(self, *a, **k):
+        pass
+
+
+def _tmax(*a):
+    m = a[0]
+    for b in a[1:]:
+        m = m if m > b else b                  # ti.max(a, b) = a > b ? a : b, folded left to right
+    return m
+
+
+def _tmin(*a):
+    m = a[0]
+    for b in a[1:]:
+        m = m if m < b else b
+    return m
+
+
+def make_taichi():
+    ti = types.ModuleType("taichi")
+    ti.cpu, ti.gpu, ti.f32, ti.f64, ti.i32 = "cpu", "gpu", np.float32, np.float64, int
+    ti.init = lambda **kw: None               # default_fp is overridden: doubles (see docstring)
+    ti.field = lambda dtype=float, shape=(): Field(dtype, shape)
+    ti.Vector = Vector
+    ti.kernel = _scoped
+    ti.func = _scoped
+    ti.ndrange, ti.grouped = ndrange, grouped
+    ti.max, ti.min, ti.abs = _tmax, _tmin, abs
+    ti.sqrt = lambda x: math.sqrt(x) if x == x and x >= 0 else float("nan")
+    ti.GUI = GUI
+    return ti
+
+
+# ----------------------------------------------------------------------------------------------
+def digest(a):
+    """sha256 of the values (+0.0 folds the sign of an exact zero, which parity does not compare)."""
+    return hashlib.sha256(np.ascontiguousarray(a + 0.0).tobytes()).hexdigest()
+
+
+def digest_steps(steps):
+    """Steps whose 19 fields are recorded as digests: 0..10, then every 10th, and the last."""
+    return sorted(set(range(0, min(steps, 10) + 1)) | set(range(0, steps + 1, 10)) | {steps})
+
+
+def run_reference(ic, steps, save_fig, full):
+    sys.modules["taichi"] = make_taichi()
+    sys.path.insert(0, REF)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    want_digest, want_full = set(digest_steps(steps)), set(full)
+    kept, rows, t0, mod = {}, [], time.time(), {}
+
+    def record(g, st):
+        if st in want_full:
+            kept[st] = {n: g[n].to_numpy() for n in STATE}
+        if st in want_digest:
+            for f in ALL_FIELDS:
+                arr = g[f].to_numpy()
+                rows.append(("%s_%d" % (f, st), digest(arr), float(arr.sum()), float(np.abs(arr).max())))
+        if st % 10 == 0:
+            print("  [ref ic%d] step %d done, %.0f s" % (ic, st, time.time() - t0), flush=True)
+
+    def hook():
+        # called by gui.get_events at the top of iteration istep (already incremented, :506-507):
+        # the fields hold the state after step istep-1.  The module's globals are the caller's.
+        if "g" not in mod:
+            mod["g"] = sys._getframe(2).f_globals
+        record(mod["g"], mod["g"]["istep"] - 1)
+
+    GUI.hook, GUI.limit = hook, steps
+    argv, cwd = sys.argv, os.getcwd()
+    work = tempfile.mkdtemp(prefix="refrun_")
+    os.chdir(work)
+    sys.argv = ["2dvof.py", "-ic", str(ic)] + (["-s"] if save_fig else [])
+    try:
+        g = runpy.run_path(os.path.join(REF, "2dvof.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    assert g["istep"] == steps
+    record(g, steps)
+    const = {k: float(g[k]) for k in ("dx", "dy", "dxi", "dyi", "dt", "Lx", "Ly", "rho_l", "rho_g", "nu_l", "nu_g")}
+    const["sigma"] = float(g["sigma"][None])
+    pngs = sorted(os.listdir(os.path.join(work, "output")))
+    return g["nx"], g["ny"], kept, rows, const, pngs, g["gui"].shown
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ic", type=int, required=True)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--full", type=int, nargs="*", default=None,
+                    help="steps whose F,u,v,p are stored in full (default 2 and the last)")
+    ap.add_argument("-s", action="store_true", help="pass -s to the reference (PNG path, needs >= 100 steps)")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    full = sorted(set(a.full if a.full is not None else (2, a.steps)) | {0})
+    nx, ny, kept, rows, const, pngs, shown = run_reference(a.ic, a.steps, a.s, full)
+    out = {"meta": np.array([nx, ny, a.ic, 0, 1]),      # same meta as make_golden.py: f64, coord cast kept
+           "steps": np.array([s for s in full if s > 0]), "nsteps": np.array(a.steps), "F_0": kept[0]["F"],
+           "const_names": np.array(sorted(const)), "const": np.array([const[k] for k in sorted(const)]),
+           "pngs": np.array(pngs), "gui_shown": np.array(shown)}
+    for st in full:
+        if st > 0:
+            for f in STATE:
+                out["%s_%d" % (f, st)] = kept[st][f]
+    # all 19 fields at digest_steps() as sha256 + two moments (diagnostics when a digest differs)
+    out["digest_names"] = np.array([r[0] for r in rows])
+    out["digest_sha256"] = np.array([r[1] for r in rows])
+    out["digest_sum"] = np.array([r[2] for r in rows])
+    out["digest_absmax"] = np.array([r[3] for r in rows])
+    path = a.out or os.path.join(HERE, "ref_ic%d_200_f64.npz" % a.ic)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
