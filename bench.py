@@ -2,8 +2,9 @@
 """bench.py -- cell-updates/s of the fused VOF time step + HBM GB/s of the Jacobi sweep.
 
     python bench.py --gpus 1 --steps K --warmup W              (4096^2 fp64 dam-break)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-                                                             (8192^2 fp64, N row strips, strong)
+    python bench.py --gpus N --steps K --warmup W              (8192^2 fp64, N row strips, strong;
+                                                                starts its own N workers)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (same, launcher-started)
 
 A "step" is one pass of the solver part of 2dvof.py's main loop (:506-528): normals + curvature,
 momentum predictor, set_BC, rhs, 10 Jacobi sweeps, velocity correction, set_BC, the two FCT
@@ -30,6 +31,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # (first sweep with update_uv 7 + second sweep 3, u / v leave for the neighbours in between) = 22
 ARRAYS_PER_STEP_FULL = 19
 ARRAYS_PER_STEP_STRIP = 22
+# algorithmic array passes per launch of the kernels of the fused step (same counting rule)
+KERNEL_PASSES = {"k_momentum": 6, "k_jacobi_tb": 3, "k_transport": 7, "k_jacobi": 3, "k_fct_x": 7, "k_fct_y": 7}
 
 
 def parse():
@@ -47,9 +50,13 @@ def parse():
     ap.add_argument("--no-scaling-reference", action="store_true",
                     help="skip the single-GPU 8192^2 leg (strong_scaling_reference_n1); used for the rocprofv3 "
                          "profiles, whose per-kernel averages must come from one grid size")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1: skip the sustained 1000-step record and the 1024^2 residual-terminated solve "
+                         "(the rocprofv3 profiles: one workload per trace)")
+    ap.add_argument("--sustained-steps", type=int, default=1000)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed/StripSolver code path even with one rank (self-test)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline's main sample")
     ap.add_argument("--dt", type=float, default=0.0,
                     help="time step (default: the reference's 4e-6, 2dvof.py:33, up to 4096^2; 1e-6 at 8192^2, where "
                          "4e-6 exceeds the explicit viscous limit dx^2/(4 nu_g) = 2.5e-6 and the reference algorithm "
@@ -62,6 +69,9 @@ def parse():
                          "kills it and tries the next carrier (default 300 + 0.01 per step; three times that for torch)")
     ap.add_argument("--no-supervisor", action="store_true", help="N > 1: run in this process, no watchdog / fallback")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N > 1: start the workers, let them find each other through the rendezvous directory and "
+                         "report -- no GPU work (self-test of the launcher)")
     ap.add_argument("--no-balance", action="store_true",
                     help="N > 1 (native exchange): keep equal strips instead of re-cutting them by the measured cost of "
                          "each rank's rows (strips.balanced_partition)")
@@ -99,54 +109,83 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(nx, ny, dtype, ic, target_s):
-    """The CPU oracle (scalar-C restatement, OpenMP over i, -O2 -ffp-contract=off = the parity
-    build) timed on this host's cores on a bounded sample of the same workload."""
-    from vof2d import _abi
+# --------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle's C restatement on this host's cores
+def _omp_threads(n):
+    """Thread count of the already loaded libgomp (the oracle reads OMP_NUM_THREADS only at load)."""
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except Exception:
+        pass
+
+
+def _time_cpu(api, nx, ny, dtype, ic, threads, target_s, max_steps=2000):
+    """(cell-updates/s, steps, seconds, Jacobi GB/s by the 24 B rule) of one oracle build."""
     from vof2d.engine import Engine, make_desc
+    _omp_threads(threads)
+    esz = 8 if dtype == "f64" else 4
+    e = Engine(api, make_desc(api, nx, ny, dtype, "f32"))
+    e.set_init_F(ic)
+    e.step(1)                      # first touch of every page
+    t0 = time.perf_counter()
+    e.step(1)
+    t1 = time.perf_counter() - t0
+    n = max(1, min(max_steps, int(target_s / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    e.step(n)
+    dt = time.perf_counter() - t0
+    # the Poisson sweep alone (:236-266 as written: rhs recomputed + copy-back), same 24 B rule as the GPU's
+    e.cal_nu_rho(); e.get_normal_young(); e.advect_upwind(); e.set_BC()
+    e.solve_p_jacobi(1)
+    ns = max(2, min(200, int(0.15 * target_s / max(t1 / 12.0, 1e-6))))
+    t0 = time.perf_counter()
+    e.solve_p_jacobi(ns)
+    ts = (time.perf_counter() - t0) / ns
+    e.close()
+    return nx * ny * n / dt, n, dt, 3 * esz * nx * ny / ts / 1e9
+
+
+def cpu_baseline(nx, ny, dtype, ic, target_s):
+    """The CPU oracle (scalar-C restatement, OpenMP over i) timed on this host's cores on a bounded
+    sample of the same workload: the parity build (-O2 -ffp-contract=off) on all usable cores and on
+    one thread, and the vectorised build (-O3 -march=native, not bit-identical) on all cores."""
+    from vof2d import _abi
     so = os.path.join(ROOT, "oracle", "_build", "libvof_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     cores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)   # read by libgomp when the oracle library loads
     api = _abi.bind(ctypes.CDLL(so), "ovof_", optional=_abi.GPU_ONLY)
-    e = Engine(api, make_desc(api, nx, ny, dtype, "f32"))
-    e.set_init_F(ic)
-    e.step(1)                      # first touch of every page
-    t0 = time.perf_counter()
-    e.step(2)
-    t1 = (time.perf_counter() - t0) / 2
-    n = max(1, min(2000, int(target_s / max(t1, 1e-6))))
-    t0 = time.perf_counter()
-    e.step(n)
-    dt = time.perf_counter() - t0
-    e.close()
+    val, n, dt, jac = _time_cpu(api, nx, ny, dtype, ic, cores, target_s)
+    one = None
+    try:
+        v1, n1, dt1, jac1 = _time_cpu(api, nx, ny, dtype, ic, 1, 0.3 * target_s, max_steps=200)
+        one = {"value": v1, "unit": "cell-updates/s", "cores": 1, "steps": n1, "seconds": dt1, "jacobi_GBs_24B_rule": jac1}
+    except Exception:
+        pass
     out_fast = None
-    try:  # BASELINE.md section 3: also the vectorised build (-O3 -march=native, contraction allowed --
-        # NOT bit-identical, timing only), compiled on this host because of -march=native
+    try:  # BASELINE.md section 3: also the vectorised build (contraction allowed -- NOT bit-identical,
+        # timing only), compiled on this host because of -march=native
         import tempfile
         tmp = tempfile.mkdtemp(prefix="vof_oracle_fast_")
         so_fast = os.path.join(tmp, "libvof_oracle_fast.so")
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-o", so_fast,
-                               os.path.join(ROOT, "oracle", "vof_oracle.c"), "-lm"],
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+                               "-o", so_fast, os.path.join(ROOT, "oracle", "vof_oracle.c"), "-lm"],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         apif = _abi.bind(ctypes.CDLL(so_fast), "ovof_", optional=_abi.GPU_ONLY)
-        ef = Engine(apif, make_desc(apif, nx, ny, dtype, "f32"))
-        ef.set_init_F(ic)
-        ef.step(1)
-        nf = max(1, n // 3)
-        t0 = time.perf_counter()
-        ef.step(nf)
-        dtf = time.perf_counter() - t0
-        ef.close()
-        out_fast = {"value": nx * ny * nf / dtf, "unit": "cell-updates/s", "cores": cores,
-                    "build": "gcc -O3 -march=native -fopenmp (not bit-identical)", "steps": nf}
+        vf, nf, dtf, jacf = _time_cpu(apif, nx, ny, dtype, ic, cores, 0.35 * target_s)
+        out_fast = {"value": vf, "unit": "cell-updates/s", "cores": cores, "jacobi_GBs_24B_rule": jacf,
+                    "build": "gcc -O3 -march=native -fopenmp (not bit-identical)", "steps": nf, "seconds": dtf}
     except Exception:
         pass
-    return {"value": nx * ny * n / dt, "unit": "cell-updates/s", "cores": cores, "kind": "port",
-            "fast_build": out_fast,
-            "sample": "%dx%d %s dam-break, %d steps after 3 warm-up steps, oracle/vof_oracle.c "
-                      "(-O2 -ffp-contract=off, OpenMP %d threads), %.1f s" % (nx, ny, dtype, n, cores, dt),
+    _omp_threads(cores)
+    return {"value": val, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "jacobi_GBs_24B_rule": jac, "threads_1": one, "fast_build": out_fast,
+            "sample": "%dx%d %s dam-break, %d steps after 2 warm-up steps, oracle/vof_oracle.c "
+                      "(-O2 -ffp-contract=off, OpenMP %d threads), %.1f s; then the same build on 1 thread and the "
+                      "-O3 -march=native build on %d threads, each on a shorter sample; jacobi_GBs_24B_rule = 3 arrays x "
+                      "sizeof(T) x cells / time of one solve_p_jacobi() call as written in 2dvof.py:236-266" % (
+                          nx, ny, dtype, n, cores, dt, cores),
             "ms_per_step": 1e3 * dt / n}
 
 
@@ -169,6 +208,95 @@ class _StdoutToStderr:
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
+
+
+def _die_with_parent():
+    # a child must not outlive the process that started it (a launcher that tears its workers down
+    # would otherwise leave GPU-holding orphans): PR_SET_PDEATHSIG = 1
+    import signal
+    ctypes.CDLL(None).prctl(1, int(signal.SIGKILL), 0, 0, 0)
+
+
+# --------------------------------------------------------------------------------------------------
+def launch_workers(a):
+    """`python bench.py --gpus N` with no launcher around it: this process becomes the launcher.  It
+    never touches the GPU (no HIP call, no torch import); it starts N fresh worker processes -- one
+    per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment exactly as
+    torch.distributed.run would set them, plus a private rendezvous directory -- relays rank 0's
+    line and exits with the first non-zero worker code."""
+    import signal
+    import socket
+    import tempfile
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rdzv = tempfile.mkdtemp(prefix="vof2d_rdzv_")        # mode 0700, unpredictable name
+    argv = [x for x in sys.argv[1:]]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VOF2D_RDZV_DIR=rdzv,
+                   VOF2D_RDZV_TAG="self_%d" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      start_new_session=True, preexec_fn=_die_with_parent))
+
+    def kill_all(*_):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)      # exactly the groups this process started
+                except ProcessLookupError:
+                    pass
+    signal.signal(signal.SIGTERM, lambda s_, f: (kill_all(), sys.exit(128 + s_)))
+    signal.signal(signal.SIGINT, lambda s_, f: (kill_all(), sys.exit(128 + s_)))
+    out0 = b""
+    rc = 0
+    try:
+        # a worker that dies takes the others down (they would wait for it until their watchdogs fire)
+        pending = set(range(a.gpus))
+        import selectors
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        eof = False
+        while pending:
+            if not eof:
+                for key, _ in sel.select(timeout=0.2):
+                    chunk = os.read(key.fileobj.fileno(), 65536)
+                    if chunk:
+                        out0 += chunk
+                    else:
+                        eof = True
+                        sel.unregister(key.fileobj)
+            else:
+                time.sleep(0.2)
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print("[bench] worker %d exited with code %d: stopping the others" % (r, code), file=sys.stderr)
+                        kill_all()
+        if not eof:
+            out0 += procs[0].stdout.read() or b""
+    finally:
+        kill_all()
+        try:
+            for n in os.listdir(rdzv):
+                p = os.path.join(rdzv, n)
+                if os.path.isdir(p):
+                    for m in os.listdir(p):
+                        os.remove(os.path.join(p, m))
+                    os.rmdir(p)
+                else:
+                    os.remove(p)
+            os.rmdir(rdzv)
+        except OSError:
+            pass
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
 
 
 def supervise(a, rank):
@@ -196,10 +324,6 @@ def supervise(a, rank):
         if x.startswith("--exchange="):
             continue
         cleaned.append(x)
-    def die_with_parent():
-        # the child must not outlive this process (a launcher that tears its workers down would
-        # otherwise leave GPU-holding orphans): PR_SET_PDEATHSIG = 1
-        ctypes.CDLL(None).prctl(1, int(signal.SIGKILL), 0, 0, 0)
 
     current = {"p": None}
 
@@ -213,10 +337,11 @@ def supervise(a, rank):
         sys.exit(128 + signum)
     signal.signal(signal.SIGTERM, on_term)
     signal.signal(signal.SIGINT, on_term)
+    base_tag = os.environ.get("VOF2D_RDZV_TAG") or str(os.getppid())
     for attempt, carrier in enumerate(carriers):
-        env = dict(os.environ, VOF2D_RDZV_TAG="%d_%d" % (os.getppid(), attempt))
+        env = dict(os.environ, VOF2D_RDZV_TAG="%s_%d" % (base_tag, attempt))
         cmd = [sys.executable, os.path.abspath(__file__)] + cleaned + ["--child", "--exchange", carrier]
-        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, preexec_fn=die_with_parent)
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, preexec_fn=_die_with_parent)
         current["p"] = p
         try:
             out, _ = p.communicate(timeout=limit if carrier == "native" else 3 * limit)
@@ -236,16 +361,103 @@ def supervise(a, rank):
     return 1
 
 
+# --------------------------------------------------------------------------------------------------
+# single-GPU extras
+def timed_steps(eng, warmup, steps):
+    eng.step(warmup)
+    eng.sync()
+    t0 = time.perf_counter()
+    eng.step(steps)
+    eng.sync()
+    return time.perf_counter() - t0
+
+
+def sustained_record(api, nx, ny, dtype, ic, local, jacobi_iters, dt, nsteps, block=100):
+    """ms/step over steps 1..nsteps of a fresh run in blocks of `block` steps (one device sync per
+    block): the default timing window (a few dozen steps right after the start) does not see the
+    regime in which the decaying front of the pressure iteration crosses the grid."""
+    from vof2d.engine import Engine, make_desc
+    e = Engine(api, make_desc(api, nx, ny, dtype, "f32", device=local, jacobi_iters=jacobi_iters, dt=dt))
+    e.set_init_F(ic)
+    e.sync()
+    blocks = []
+    t_all = time.perf_counter()
+    for _ in range(max(1, nsteps // block)):
+        t0 = time.perf_counter()
+        e.step(block)
+        e.sync()
+        blocks.append(1e3 * (time.perf_counter() - t0) / block)
+    total = time.perf_counter() - t_all
+    n = block * len(blocks)
+    viol = e.get_counter("courant_violations")
+    e.close()
+    return {"steps": n, "block": block, "ms_per_step_blocks": [round(b, 4) for b in blocks],
+            "ms_per_step": 1e3 * total / n, "ms_per_step_worst_block": max(blocks),
+            "value": nx * ny * n / total, "unit": "cell-updates/s", "courant_violations": viol,
+            "note": "steps 1..%d from set_init_F, wall clock incl. one sync per block" % n}
+
+
+def residual_solve_1024(api, local, dtype="f64", tol=1e-6, cap=3000000, every=5000):
+    """BASELINE configs[1]: 1024^2 dam-break, the first pressure solve of the run (p = 0 start) iterated
+    until max|p_new - p| / max|p_new| <= 1e-6 (vof_solve_p, relative criterion of SURVEY 8f-1) instead
+    of the reference's fixed 10 sweeps.  Five sweeps per launch; the norms are reduced in the last
+    launch before each check."""
+    from vof2d.engine import Engine, make_desc
+    n = 1024
+    e = Engine(api, make_desc(api, n, n, dtype, "f32", device=local))
+    e.set_init_F(1)
+    e.cal_nu_rho(); e.get_normal_young(); e.advect_upwind(); e.set_BC()    # :513-518 of step 1
+    e.solve_p_jacobi(10)                                                    # (warm the kernels; 10 sweeps of the solve)
+    e.sync()
+    t0 = time.perf_counter()
+    it, res = e.solve_p(tol, cap, every, "rel")
+    ms = 1e3 * (time.perf_counter() - t0)
+    e.close()
+    esz = 8 if dtype == "f64" else 4
+    return {"workload": "1024x1024 -ic 1 %s, pressure solve of step 1 from p = 0" % dtype,
+            "criterion": "max|p_new-p| / max(max|p_new|, 1e-300) <= %g, checked every %d sweeps" % (tol, every),
+            "iterations": it + 10, "residual": res, "converged": bool(res <= tol), "ms": ms,
+            "sweeps_per_s": it / (ms * 1e-3), "us_per_sweep": 1e3 * ms / max(it, 1),
+            "algorithmic_GBs_24B_rule": 3 * esz * n * n * it / (ms * 1e-3) / 1e9,
+            "note": "1024^2 (3 x 8.4 MB) sits in L2 / MALL: cache bandwidth, not HBM; the relative residual of this "
+                    "pure-Neumann iteration tends to 1/k (the null-space constant), so 1e-6 takes ~1e6 sweeps on any grid"}
+
+
+def single_gpu_reference(api, n, dtype, ic, local, jacobi_iters, dt, steps=12):
+    from vof2d.engine import Engine, make_desc
+    e = Engine(api, make_desc(api, n, n, dtype, "f32", device=local, jacobi_iters=jacobi_iters, dt=dt))
+    e.set_init_F(ic)
+    el = timed_steps(e, 3, steps)
+    e.close()
+    return {"workload": "%dx%d -ic %d %s dt %g, single strip (the grid bench.py --gpus N > 1 strong-scales)" % (n, n, ic, dtype, dt),
+            "value": n * n * steps / el, "unit": "cell-updates/s", "ms_per_step": 1e3 * el / steps, "steps": steps}
+
+
+# --------------------------------------------------------------------------------------------------
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not a.child:
+        raise SystemExit(launch_workers(a))       # no launcher around us: be the launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d (start `python bench.py --gpus N` without a launcher, "
+                         "or with python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                         "--master-port P bench.py --gpus N)" % (a.gpus, world))
+    if a.dry_run:
+        if os.environ.get("VOF2D_BENCH_TEST_DIE_RANK") == str(rank):      # self-test of the launcher's clean-up
+            sys.exit(7)
+        from vof2d.comms import EnvComm
+        comm = EnvComm(rank, world, local)
+        token = comm.broadcast_object({"token": os.getpid()} if rank == 0 else None)
+        got = comm.gather_object({"rank": rank, "local_rank": local, "world": world, "token": token["token"],
+                                  "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))})
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": got}), flush=True)
+            time.sleep(0.2)
+            comm.cleanup()
+        return
     if (world > 1 or a.force_dist) and not a.child and not a.no_supervisor:
         raise SystemExit(supervise(a, rank))
     if os.environ.get("VOF2D_BENCH_TEST_HANG") == a.exchange and a.child:   # self-test of the watchdog
@@ -262,6 +474,7 @@ def main():
     dist_path = world > 1 or a.force_dist
     comm = None
     exchange = "none"
+    api = None
     if not dist_path:
         # single GPU: no torch in the process at all -- ctypes -> C ABI -> HIP
         from vof2d._lib import hip_api
@@ -269,12 +482,7 @@ def main():
         api = hip_api()
         eng = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters, dt=dt))
         eng.set_init_F(a.ic)
-        eng.step(a.warmup)
-        eng.sync()
-        t0 = time.perf_counter()
-        eng.step(a.steps)
-        eng.sync()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed_steps(eng, a.warmup, a.steps)
         solver = None
     native_ok = False
     if dist_path and a.exchange == "native":
@@ -284,6 +492,7 @@ def main():
         from vof2d.strips import StripSolver
         try:
             comm = EnvComm(rank, world, local)
+
             def make_solver(parts=None):
                 with _StdoutToStderr():
                     return StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local, parts=parts,
@@ -292,43 +501,55 @@ def main():
             parts = solver.parts
             if (world > 1 or os.environ.get("VOF2D_BENCH_TEST_BALANCE")) and not a.no_balance:   # (env: self-test of this block with one rank)
                 # Strips do not cost the same: rows of gas take the sweeps' zero shortcuts, the liquid and
-                # the interface do not (and GPUs differ a little).  Time each rank's own kernels on the
-                # equal strips (no exchange: the halos go stale, the state is thrown away), re-cut the rows
-                # so that every rank gets the same share of the cost, and start again from the initial
-                # condition.  Results do not depend on the partition.
-                import pickle
+                # the interface do not (and GPUs differ a little).  Time each rank's strip on the equal
+                # partition, re-cut the rows so that every rank gets the same share of the cost, and
+                # start again from the initial condition.  Results do not depend on the partition.
+                # The probe times the rank's own kernels on VALID data (the kernels are data dependent: zero
+                # shortcuts, division tiers -- stale halos would feed them garbage rows): one kernel-only
+                # step, timed on the device, then a full halo exchange before the next one (a deep halo
+                # covers exactly one step).  Waiting for neighbours is not in the figure, or every rank
+                # would read the slowest rank's time.  A failure on one rank is agreed on before anybody
+                # changes partition.
                 from vof2d.strips import balanced_partition
                 for _round in range(2):    # the second cut corrects what the piecewise-uniform cost model of the first missed
-                    solver.eng.step(3)
-                    solver.eng.sync()
-                    t0 = time.perf_counter()
-                    solver.eng.step(8)
-                    solver.eng.sync()
-                    cost = (time.perf_counter() - t0) / 8
-                    costs = comm.gather_object(cost)
-                    blob = None
-                    if rank == 0:
-                        try:
-                            if max(costs) <= (1.015, 1.03)[_round] * sum(costs) / len(costs):
-                                blob = pickle.dumps(None)          # balanced within 1.5 % (3 % after one cut: chunk
-                                                                   # lengths quantise a strip's cost): keep these strips
-                            else:
-                                blob = pickle.dumps(balanced_partition(nx, parts, costs, min_rows=solver.halo))
-                        except Exception as exc:      # keep every rank on the same partition whatever happens here
-                            print("[bench] cost balancing failed (%r): keeping the strips" % (exc,), file=sys.stderr)
-                            blob = pickle.dumps(None)
-                    new_parts = pickle.loads(comm.broadcast_bytes(blob))
+                    cost, failed = 0.0, 0.0
+                    try:
+                        with _StdoutToStderr():
+                            samples = []
+                            for _k in range(10):
+                                solver.eng.timer_start()
+                                solver.eng.step(1)
+                                samples.append(solver.eng.timer_stop())   # ms of this rank's stream
+                                solver.exchange()
+                            cost = sum(samples[2:]) / len(samples[2:])
+                    except Exception as exc:
+                        print("[bench] rank %d: cost probe failed (%r)" % (rank, exc), file=sys.stderr)
+                        failed = 1.0
+                    failed = comm.allreduce_max(failed, solver.eng)     # every rank leaves the block together
+                    new_parts = None
+                    if not failed:
+                        costs = comm.gather_object(cost)
+                        decision = None
+                        if rank == 0:
+                            try:
+                                if max(costs) > (1.015, 1.03)[_round] * sum(costs) / len(costs):
+                                    decision = balanced_partition(nx, parts, costs, min_rows=solver.halo)
+                                # else: balanced within 1.5 % (3 % after one cut: chunk lengths quantise a strip's cost)
+                            except Exception as exc:      # keep every rank on the same partition whatever happens here
+                                print("[bench] cost balancing failed (%r): keeping the strips" % (exc,), file=sys.stderr)
+                        new_parts = comm.broadcast_object(decision)
                     solver.barrier()
                     with _StdoutToStderr():
                         solver.close()
                     if new_parts is not None:
-                        parts = new_parts
-                    solver = make_solver(parts)       # from the initial condition again (the timing steps let the halos go stale)
+                        parts = [tuple(pr) for pr in new_parts]
+                    solver = make_solver(parts)       # from the initial condition again
                     if new_parts is None:
                         break
             native_ok = True
         except Exception as exc:   # e.g. no loadable RCCL: symmetric on all ranks -> the torch carrier
             print("[bench] native RCCL exchange unavailable (%r); falling back to torch.distributed" % (exc,), file=sys.stderr)
+    graph_steps = None
     if not dist_path:
         pass
     elif native_ok:
@@ -337,12 +558,14 @@ def main():
             solver.step(a.warmup, overlap=a.overlap)
             eng.sync()
             solver.barrier()
+        g0 = eng.get_counter("exchange_graph_steps") if world > 1 else 0
         t0 = time.perf_counter()
         solver.step(a.steps, overlap=a.overlap)
         eng.sync()          # the compute stream has joined the communication stream of every step
         solver.barrier()
         elapsed = time.perf_counter() - t0
         elapsed = comm.allreduce_max(elapsed, eng)
+        graph_steps = (eng.get_counter("exchange_graph_steps") - g0) if world > 1 else None
         exchange = solver.exchange_kind if world > 1 else "none"
     else:
         import torch
@@ -401,44 +624,50 @@ def main():
         from vof2d.engine import Engine as _E, make_desc as _md
         e0 = _E(api, _md(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=0, dt=dt))
         e0.set_init_F(a.ic)
-        e0.step(a.warmup)
-        e0.sync()
-        t0 = time.perf_counter()
-        e0.step(a.steps)
-        e0.sync()
-        ms0 = 1e3 * (time.perf_counter() - t0) / a.steps
+        ms0 = 1e3 * timed_steps(e0, a.warmup, a.steps) / a.steps
         e0.close()
         launches = a.jacobi_iters // tb
         us_in_step = (1e3 * elapsed / a.steps - ms0) * 1e3 / launches
         fused.update({"us_per_launch_in_step": us_in_step, "us_per_sweep_in_step": us_in_step / tb,
                       "ms_per_step_without_sweeps": ms0,
-                      "algorithmic_GBs_in_step": sweep_bytes * tb / (us_in_step * 1e-6) / 1e9})
+                      "algorithmic_GBs_in_step": sweep_bytes * tb / (us_in_step * 1e-6) / 1e9,
+                      "frac_of_peak_on_its_3_passes": sweep_bytes / (us_in_step * 1e-6) / 1e9 / HBM_PEAK_GBS})
     # The N > 1 runs strong-scale 8192^2; give the single-GPU figure for that grid too, so the
-    # scaling series has its own N = 1 point (only when the workload was not overridden).
+    # scaling series has its own N = 1 point: in the N = 1 line (default workload only), and --
+    # measured in the same job, on rank 0's GPU, after the timed region -- in every N > 1 line.
     ref8192 = None
-    if not dist_path and not a.nx and rank == 0 and not a.no_scaling_reference:
+    speedup = None
+    if rank == 0 and not a.no_scaling_reference and ((not dist_path and not a.nx) or (world > 1 and nx == ny)):
         try:
-            from vof2d.engine import Engine as _E2, make_desc as _md2
-            e8 = _E2(api, _md2(api, 8192, 8192, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters, dt=stable_dt(8192)))
-            e8.set_init_F(a.ic)
-            e8.step(3)
-            e8.sync()
-            t0 = time.perf_counter()
-            e8.step(12)
-            e8.sync()
-            dt8 = time.perf_counter() - t0
-            e8.close()
-            ref8192 = {"workload": "8192x8192 -ic %d %s dt %g, single strip (the grid bench.py --gpus N > 1 strong-scales)" % (
-                a.ic, a.dtype, stable_dt(8192)), "value": 8192 * 8192 * 12 / dt8, "unit": "cell-updates/s", "ms_per_step": 1e3 * dt8 / 12,
-                "steps": 12}
+            if api is None:
+                from vof2d._lib import hip_api
+                api = hip_api()
+            nref = 8192 if not dist_path else nx
+            ref8192 = single_gpu_reference(api, nref, a.dtype, a.ic, local, a.jacobi_iters, stable_dt(nref))
+            if dist_path:
+                speedup = (nx * ny * a.steps / elapsed) / ref8192["value"]
         except Exception as exc:   # e.g. not enough free HBM
             ref8192 = {"error": str(exc)}
     prof = eng.profile_steps(14) if not dist_path else {}
     kernels_us = {k: round(v[0], 2) for k, v in prof.items()}
+    cells = nx * ny
+    step_kernels = {k: {"launches_per_step": round(v[1] / 14.0, 2), "algorithmic_passes": KERNEL_PASSES[k],
+                        "algorithmic_bytes_per_launch": KERNEL_PASSES[k] * esz * cells, "us_per_launch_dispatch": round(v[0], 2),
+                        "frac_of_peak": KERNEL_PASSES[k] * esz * cells / (v[0] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                    for k, v in prof.items() if k in KERNEL_PASSES and v[0] > 0}
 
+    # which schedule actually ran: the 19-pass one-kernel transport needs a full domain, or mode 4 with
+    # EVERY timed step replayed from the captured exchange graph (an RCCL that cannot capture, or
+    # VOF2D_XCHG_GRAPH=0, silently runs mode 4 as eager mode 1 with the two-kernel transport)
+    effective_overlap = a.overlap if dist_path else None
     try:
-        one_kernel_transport = (bool(eng.get_param("fuse_transport")) and exchange == "none") or \
-                               (exchange == "native" and a.overlap == 4)
+        if exchange == "native":
+            captured = eng.comm_info()[1] == 1 and graph_steps == a.steps
+            if a.overlap == 4 and not captured:
+                effective_overlap = 1
+            one_kernel_transport = a.overlap == 4 and captured
+        else:
+            one_kernel_transport = bool(eng.get_param("fuse_transport")) and exchange == "none"
     except Exception:
         one_kernel_transport = False
     ARRAYS_PER_STEP = ARRAYS_PER_STEP_FULL if one_kernel_transport else ARRAYS_PER_STEP_STRIP
@@ -456,12 +685,16 @@ def main():
             "data": "synthetic (set_init_F -ic %d generated on device)" % a.ic,
             "config": {"workload": "%dx%d -ic %d %s, dt %g, %d Jacobi sweeps/step, %s" % (
                 nx, ny, a.ic, a.dtype, dt, a.jacobi_iters, "single strip" if not dist_path else
-                "%d row strips, %d-row deep halo, per-field RCCL send/recv (%s) overlap mode %d" % (
-                    world, solver.halo, exchange, a.overlap)),
+                "%d row strips, %d-row deep halo, per-field RCCL send/recv (%s) overlap mode %d%s" % (
+                    world, solver.halo, exchange, a.overlap,
+                    "" if effective_overlap == a.overlap else " requested, ran as mode %d (exchange not captured)" % effective_overlap)),
                 "nx": nx, "ny": ny, "dt": dt, "jacobi_iters": a.jacobi_iters,
                 "exchange": exchange, "overlap": a.overlap if dist_path else None,
+                "overlap_effective": effective_overlap,
                 "rows_per_rank": [hi - lo + 1 for lo, hi in solver.parts] if dist_path else None,
                 "exchange_graph": (eng.comm_info()[1] == 1) if exchange == "native" else None,
+                "exchange_graph_steps_in_timed_region": graph_steps,
+                "multi_gpu_hardware_verified": False if world > 1 else None,
                 "arrays_per_cell_update": ARRAYS_PER_STEP,
                 "bytes_per_cell_update_algorithmic": ARRAYS_PER_STEP * esz},
             # The Poisson Jacobi kernel (north star): algorithmic bytes = 3 arrays x sizeof(T) x
@@ -472,11 +705,26 @@ def main():
                          "us_per_launch": 1e3 * ms_sweep_1, "algorithmic_bytes_per_launch": sweep_bytes,
                          "launches_timed": max(2, a.jacobi_sweeps_timed // 2 * 2)},
             "jacobi_fused": fused,
+            # the kernels the step itself runs, same counting rule (built-in profiler: dispatch start ->
+            # stop; reads a few us high behind a long-tailed predecessor -- rocprofv3, profiles/, is the reference)
+            "step_kernels": step_kernels,
             "strong_scaling_reference_n1": ref8192,
+            "speedup_same_grid": speedup,
             "step_hbm_gbs_algorithmic": ARRAYS_PER_STEP * esz * nx * ny * a.steps / elapsed / 1e9,
+            "step_frac_of_peak_algorithmic": ARRAYS_PER_STEP * esz * nx * ny * a.steps / elapsed / 1e9 / HBM_PEAK_GBS,
             "kernels_us_dispatch_start_to_stop": kernels_us,
             "courant_violations": violations,
         }
+        if not dist_path and not a.no_extras:
+            try:
+                out["sustained"] = sustained_record(api, nx, ny, a.dtype, a.ic, local, a.jacobi_iters, dt, a.sustained_steps)
+            except Exception as exc:
+                out["sustained"] = {"error": str(exc)}
+            if not a.nx:      # default workload only
+                try:
+                    out["residual_solve_1024"] = residual_solve_1024(api, local)
+                except Exception as exc:
+                    out["residual_solve_1024"] = {"error": str(exc)}
         if not dist_path and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, a.dtype, a.ic, a.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -12,9 +12,32 @@ Two carriers with the same four methods (`broadcast_bytes`, `allreduce_max`, `ba
   rendezvous directory on the node, and reductions run on the library's own RCCL communicator
   (vof_comm_allreduce_max).  One node only -- which is what row strips over xGMI are for.
 """
+import io
+import json
 import os
-import pickle
+import stat
 import time
+
+import numpy as np
+
+
+def _dumps(obj):
+    """Rendezvous payloads are data, never code: JSON for plain values, the .npy format (no pickled
+    objects) for arrays.  Nothing read from the rendezvous directory is ever unpickled."""
+    if isinstance(obj, np.ndarray):
+        buf = io.BytesIO()
+        np.save(buf, obj, allow_pickle=False)
+        return b"NPY0" + buf.getvalue()
+    return b"JSN0" + json.dumps(obj).encode()
+
+
+def _loads(data):
+    tag, body = data[:4], data[4:]
+    if tag == b"NPY0":
+        return np.load(io.BytesIO(body), allow_pickle=False)
+    if tag == b"JSN0":
+        return json.loads(body.decode())
+    raise ValueError("rendezvous: unknown payload tag %r" % (tag,))
 
 
 class TorchComm:
@@ -40,30 +63,55 @@ class TorchComm:
         self.dist.gather_object(obj, parts, dst=0)
         return parts
 
+    def broadcast_object(self, obj, engine=None):
+        box = [obj if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
 
 class EnvComm:
-    """torch-free carrier for one node (see module docstring)."""
+    """torch-free carrier for one node (see module docstring).
+
+    The rendezvous directory is private to the launch: `bench.py --gpus N` started without a
+    launcher creates it with tempfile.mkdtemp (mode 0700, unpredictable name) and hands it to its
+    workers in VOF2D_RDZV_DIR.  Under an external launcher the name is derived from the launcher's
+    port / run id / restart count / pid, and the directory is refused unless it is a real directory
+    owned by this user with no access for anybody else."""
 
     def __init__(self, rank=None, world=None, local_rank=None, rdzv_dir=None, timeout=300.0):
         env = os.environ
         self.rank = int(env.get("RANK", 0)) if rank is None else rank
         self.world = int(env.get("WORLD_SIZE", 1)) if world is None else world
         self.local_rank = int(env.get("LOCAL_RANK", self.rank)) if local_rank is None else local_rank
-        # one directory per launch: the launcher's pid (the workers' common parent) and its port
-        # (VOF2D_RDZV_TAG: set by a supervising parent process, whose own parent the workers share)
-        tag = "%s_%s_%s" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"),
-                            env.get("VOF2D_RDZV_TAG") or os.getppid())
-        self.dir = rdzv_dir or os.path.join(env.get("VOF2D_RDZV_DIR", "/tmp"), "vof2d_rdzv_" + tag)
-        os.makedirs(self.dir, exist_ok=True)
+        # one directory per launch AND per restart of it: a restarted torchrun keeps its pid, port and
+        # run id, but counts its restarts (stale files of the crashed attempt stay behind, unread)
+        tag = "%s_%s_%s_%s" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"),
+                               env.get("TORCHELASTIC_RESTART_COUNT", "0"), env.get("VOF2D_RDZV_TAG") or os.getppid())
+        base = env.get("VOF2D_RDZV_DIR") or os.path.join("/tmp", "vof2d-%d" % os.getuid())
+        self._private_dir(base)
+        self.dir = rdzv_dir or os.path.join(base, "rdzv_" + tag)
+        self._private_dir(self.dir)
         self.timeout = timeout
         self._seq = 0
+
+    @staticmethod
+    def _private_dir(path):
+        try:
+            os.mkdir(path, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(path)                     # lstat: a symlink planted by somebody else is refused
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError("rendezvous directory %s is not a private directory of uid %d "
+                                  "(mode %o, owner %d)" % (path, os.getuid(), st.st_mode & 0o7777, st.st_uid))
 
     def _path(self, name, rank=None):
         return os.path.join(self.dir, name if rank is None else "%s.%d" % (name, rank))
 
     def _put(self, path, data):
         tmp = "%s.tmp%d" % (path, os.getpid())
-        with open(tmp, "wb") as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(data)
         os.replace(tmp, path)   # atomic: readers see the whole file or none
 
@@ -77,12 +125,17 @@ class EnvComm:
             return f.read()
 
     def broadcast_bytes(self, data, engine=None):
+        """Raw bytes from rank 0 to everybody (e.g. the 128-byte RCCL unique id)."""
         self._seq += 1
         path = self._path("bcast%d" % self._seq)
         if self.rank == 0:
-            self._put(path, data)
+            self._put(path, bytes(data))
             return data
         return self._get(path)
+
+    def broadcast_object(self, obj, engine=None):
+        """A JSON-able value (or an array) from rank 0 to everybody."""
+        return _loads(self.broadcast_bytes(_dumps(obj) if self.rank == 0 else None))
 
     def allreduce_max(self, value, engine=None):
         if self.world == 1:
@@ -97,10 +150,10 @@ class EnvComm:
     def gather_object(self, obj):
         self._seq += 1
         name = "gather%d" % self._seq
-        self._put(self._path(name, self.rank), pickle.dumps(obj))
+        self._put(self._path(name, self.rank), _dumps(obj))
         if self.rank != 0:
             return None
-        return [pickle.loads(self._get(self._path(name, r))) for r in range(self.world)]
+        return [_loads(self._get(self._path(name, r))) for r in range(self.world)]
 
     def cleanup(self):
         """Remove this launch's rendezvous files (rank 0, after a barrier)."""

@@ -1,0 +1,164 @@
+"""Worker of tests/test_host_gpu.py::test_native_rccl_exchange_* -- run as a FRESH process that
+never imports torch, so that the library binds the system RCCL (ROCm 7.2: 2.27.7, whose send/recv
+groups can be captured into the step graph) and not the 2.26.6 PyTorch bundles, and the captured
+exchange -- what `bench.py --gpus N` runs by default -- is what is asserted, strictly.
+
+    python tests/_loopback_worker.py modes | mode4 LO HI
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "taichi-2d-vof_amd"), os.path.join(ROOT, "tests")]
+
+
+@contextlib.contextmanager
+def raises(exc):
+    try:
+        yield
+    except exc:
+        return
+    raise AssertionError("%s not raised" % exc.__name__)
+
+
+def native_rccl_exchange_loopback(hip_api):
+    """vof_comm_init / vof_comm_exchange / vof_step_exchange on one GPU with both neighbours looped
+    back to the calling rank: each halo must receive the W owned rows next to it (RCCL pairs the k-th
+    send to a peer with the k-th receive from it) -- checks row ranges, byte counts, the F buffer
+    swap and the stream ordering of the in-library exchange."""
+    from vof2d import _abi
+    from vof2d.engine import Engine, make_desc, comm_unique_id, VofError
+    nx, ny, W = 160, 96, _abi.halo_rows(10)
+    own = (41, 120)
+    rows = (own[0] - W, own[1] + W)
+    e = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
+    e.set_init_F(1)
+    with raises(VofError):
+        e.step_exchange(1)                      # no communicator yet
+    uid = comm_unique_id(hip_api)
+    assert len(uid) == _abi.VOF_COMM_ID_BYTES
+    with raises(VofError):
+        e.comm_init(uid, 0, 1)                  # an interior strip cannot be rank 0 of 1
+    e.comm_init(uid, 0, 1, loopback=True)
+    rng = np.random.default_rng(5)
+    for f in ("F", "u", "v", "p"):
+        e.set(f, rng.random((rows[1] - rows[0] + 1, ny + 2)), rows)
+    before = {f: e.get(f, rows) for f in ("F", "u", "v", "p")}
+    e.comm_exchange(_abi.VOF_XCHG_F | _abi.VOF_XCHG_P)
+    e.sync()
+    lo, hi = own[0] - rows[0], own[1] - rows[0]    # array indices of own_lo / own_hi
+    for f in ("F", "u", "v", "p"):
+        got, was = e.get(f, rows), before[f]
+        if f in ("F", "p"):
+            assert np.array_equal(got[lo - W:lo], was[lo:lo + W]), f
+            assert np.array_equal(got[hi + 1:hi + 1 + W], was[hi - W + 1:hi + 1]), f
+            assert np.array_equal(got[lo:hi + 1], was[lo:hi + 1]), f
+        else:
+            assert np.array_equal(got, was), f
+    # the stepping loop: same result as the phases with a loopback copy after each, done by hand
+    ref = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
+    for f in ("F", "u", "v", "p"):
+        ref.set(f, e.get(f, rows), rows)
+    ref.istep = e.istep
+
+    def loop(fields):
+        for f in fields:
+            a = ref.get(f, rows)
+            a[lo - W:lo] = a[lo:lo + W]
+            a[hi + 1:hi + 1 + W] = a[hi - W + 1:hi + 1]
+            ref.set(f, a, rows)
+
+    # non-overlapped: deterministic, equal to the hand-made copies on every stored row.  The first
+    # step of a communicator is launched eagerly, later ones replay one captured graph per parity.
+    e.step_exchange(5, 0)
+    for _ in range(5):
+        for ph in (0, 1, 2):
+            ref.step_phase(ph)
+        loop(("F", "u", "v", "p"))
+    for f in ("F", "u", "v", "p"):
+        assert np.array_equal(e.get(f, rows), ref.get(f, rows), equal_nan=True), f
+    # overlapped: with a looped-back neighbour the halos change *value* under the running kernels
+    # (between real neighbours they are rewritten with identical values), so rows near the edges
+    # depend on timing here.  Deterministic and checked: every halo ends up holding the final
+    # owned rows next to it, and rows deeper than one step's dependency cone equal the reference.
+    for mode in (1, 2, 3, 1, 2, 3, 2, 1, 4, 4, 4, 1, 4, 4, 2, 4, 3, 4):   # 4: fused transport, one F / twin swap per step
+        for f in ("F", "u", "v", "p"):
+            ref.set(f, e.get(f, rows), rows)
+        ref.istep = e.istep
+        e.step_exchange(1, mode)
+        if mode == 4:   # all four fields together once the edge bands of the fused transport exist
+            ref.step_phase(0); ref.step_phase(1); ref.step_phase(2); loop(("p", "u", "v", "F"))
+        else:
+            ref.step_phase(0); loop(("p",)); ref.step_phase(1); loop(("u", "v")); ref.step_phase(2); loop(("F",))
+        for f in ("F", "u", "v", "p"):
+            got = e.get(f, rows)
+            assert np.array_equal(got[lo - W:lo], got[lo:lo + W], equal_nan=True), (f, mode)
+            assert np.array_equal(got[hi + 1:hi + 1 + W], got[hi - W + 1:hi + 1], equal_nan=True), (f, mode)
+            assert np.array_equal(got[lo + W:hi + 1 - W], ref.get(f, rows)[lo + W:hi + 1 - W], equal_nan=True), (f, mode)
+    # one captured graph per (parity, mode): this process has no torch in it, so the library binds the
+    # system RCCL (ROCm 7.2: 2.27.7), whose send/recv groups can be captured -- required, not optional
+    version, graphs = e.comm_info()
+    assert version >= 22707, "RCCL %d cannot capture the exchange" % version
+    assert graphs == 1 and e.get_counter("exchange_graph_steps") >= 18      # (a communicator's first step is eager)
+    e.comm_destroy()
+    e.close(); ref.close()
+
+
+def exchange_mode4_equals_phases_plus_copies(hip_api, own):
+    """vof_step_exchange overlap 4 (fused transport on the edge bands, one send/recv group, fused
+    transport on the other rows) on an interior strip, on the strips next to the left / right wall (one
+    band only) and on a strip so thin that its bands meet, neighbours looped back.  Nothing the second transport launch reads is being
+    received meanwhile, so -- unlike modes 1-3 on a loopback -- the result is deterministic and must
+    equal the phased step followed by hand-made halo copies on every stored row, ghost cells included."""
+    from vof2d import _abi
+    from vof2d.engine import Engine, make_desc, comm_unique_id
+    nx, ny, W = 160, 96, _abi.halo_rows(10)
+    rows = (max(0, own[0] - W), min(nx + 1, own[1] + W))
+    wall_lo, wall_hi = own[0] == 1, own[1] == nx
+    e = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
+    ref = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
+    for x in (e, ref):
+        x.set_init_F(3)
+    e.comm_init(comm_unique_id(hip_api), 0, 1, loopback=True)
+    lo, hi = own[0] - rows[0], own[1] - rows[0]
+
+    def loop(fields):
+        for f in fields:
+            a = ref.get(f, rows)
+            if not wall_lo:
+                a[lo - W:lo] = a[lo:lo + W]
+            if not wall_hi:
+                a[hi + 1:hi + 1 + W] = a[hi - W + 1:hi + 1]
+            ref.set(f, a, rows)
+
+    for n in (1, 1, 3, 2):   # the first step of a communicator is eager (and runs as mode 1), later ones are captured
+        if e.istep == 0:
+            e.step_exchange(1, 0); ref_modes = 1
+        else:
+            e.step_exchange(n, 4); ref_modes = n
+        for _ in range(ref_modes):
+            for ph in (0, 1, 2):
+                ref.step_phase(ph)
+            loop(("p", "u", "v", "F"))
+        # the captured path is REQUIRED here (fresh torch-free process, system RCCL): mode 4 is
+        # deterministic on a loopback and must equal the phased step + copies on every stored row
+        assert e.comm_info()[1] == 1, "exchange graph capture unavailable (RCCL %d)" % e.comm_info()[0]
+        for f in ("F", "u", "v", "p"):
+            got, want = e.get(f, rows), ref.get(f, rows)
+            assert np.array_equal(got, want, equal_nan=True), (own, f, int(e.istep), np.argwhere(got != want)[:4])
+    assert e.get_counter("exchange_graph_steps") >= 5      # every step but the communicator's first (and one after dirty ghosts)
+    e.comm_destroy(); e.close(); ref.close()
+
+
+if __name__ == "__main__":
+    from vof2d._lib import hip_api as load
+    api = load()
+    if sys.argv[1] == "modes":
+        native_rccl_exchange_loopback(api)
+    else:
+        exchange_mode4_equals_phases_plus_copies(api, (int(sys.argv[2]), int(sys.argv[3])))
+    assert "torch" not in sys.modules, "the worker must stay torch-free"
+    print("OK")

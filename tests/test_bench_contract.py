@@ -14,7 +14,7 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nx", "512", "--steps", "6", "--warmup", "2",
-                        "--jacobi-sweeps-timed", "20", "--cpu-seconds", "0.5"], capture_output=True, text=True,
+                        "--jacobi-sweeps-timed", "20", "--cpu-seconds", "0.5", "--sustained-steps", "200"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -31,6 +31,23 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "oracle/vof_oracle.c" in cb["sample"]
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert cb["threads_1"]["cores"] == 1 and cb["threads_1"]["value"] > 0 and cb["jacobi_GBs_24B_rule"] > 0
+    sus = d["sustained"]
+    assert sus["steps"] == 200 and len(sus["ms_per_step_blocks"]) == 2 and sus["value"] > 0
+    for k in ("k_momentum", "k_jacobi_tb", "k_transport"):
+        assert 0 < d["step_kernels"][k]["frac_of_peak"] < 1.5      # 512^2 sits in cache: may exceed the HBM figure
+
+
+@pytest.mark.gpu
+def test_bench_default_workload_reports_the_1024_residual_solve():
+    """BASELINE configs[1] as a bench leg (small step counts elsewhere to keep it short)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
+                        "--jacobi-sweeps-timed", "20", "--no-cpu-baseline", "--no-scaling-reference",
+                        "--sustained-steps", "100"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    rs = d["residual_solve_1024"]
+    assert rs["converged"] and rs["residual"] <= 1e-6 and 500000 <= rs["iterations"] < 3000000 and rs["sweeps_per_s"] > 1e4
 
 
 def test_bench_refuses_a_gpu_count_that_does_not_match_the_launcher():
@@ -38,3 +55,60 @@ def test_bench_refuses_a_gpu_count_that_does_not_match_the_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=120, env=env)
     assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items()
+            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VOF2D_RDZV_DIR", "VOF2D_RDZV_TAG")}
+
+
+def test_bench_starts_its_own_workers_when_no_launcher_did():
+    """`python bench.py --gpus N` with WORLD_SIZE unset: the (GPU-free) parent spawns N workers with
+    the launcher's environment, they meet in a private rendezvous directory, rank 0's line is relayed.
+    --dry-run: no GPU work, so this runs here."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True,
+                       text=True, timeout=120, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and [x["rank"] for x in d["ranks"]] == [0, 1, 2, 3]
+    assert [x["local_rank"] for x in d["ranks"]] == [0, 1, 2, 3] and all(x["world"] == 4 for x in d["ranks"])
+    assert len({x["token"] for x in d["ranks"]}) == 1 and len({x["master"] for x in d["ranks"]}) == 1
+    assert d["ranks"][0]["master"].startswith("127.0.0.1:")
+
+
+def test_self_started_run_ends_when_a_worker_dies():
+    """A worker that exits non-zero takes the launch down with its code instead of leaving the
+    others waiting (here: every worker refuses --steps -1 before touching anything)."""
+    env = dict(_clean_env(), VOF2D_BENCH_TEST_DIE_RANK="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode == 7 and "worker 1 exited with code 7" in r.stderr
+
+
+def test_rendezvous_directory_must_be_private(tmp_path):
+    from vof2d.comms import EnvComm
+    d = tmp_path / "shared"
+    d.mkdir(mode=0o755)
+    os.chmod(d, 0o755)
+    with pytest.raises(PermissionError):
+        EnvComm(0, 1, 0, rdzv_dir=str(d))
+    link = tmp_path / "link"
+    target = tmp_path / "target"
+    target.mkdir(mode=0o700)
+    link.symlink_to(target)
+    with pytest.raises(PermissionError):
+        EnvComm(0, 1, 0, rdzv_dir=str(link))
+    ok = EnvComm(0, 1, 0, rdzv_dir=str(tmp_path / "fresh"))
+    assert (os.stat(ok.dir).st_mode & 0o777) == 0o700
+    # payloads are data: JSON or .npy, never pickle
+    import numpy as np
+    assert ok.gather_object({"a": [1, 2.5]}) == [{"a": [1, 2.5]}]
+    assert np.array_equal(ok.gather_object(np.arange(6.0).reshape(2, 3))[0], np.arange(6.0).reshape(2, 3))
+    with open(os.path.join(ok.dir, "bcast1"), "wb") as f:
+        import pickle
+        f.write(pickle.dumps({"evil": 1}))
+    ok2 = EnvComm(1, 2, 1, rdzv_dir=ok.dir)
+    with pytest.raises(ValueError):
+        ok2.broadcast_object(None)

@@ -94,139 +94,25 @@ def test_display_fields(hip_api, oracle_api):
         strip.vis_field("vof")
 
 
-def test_native_rccl_exchange_loopback(hip_api):
+def _loopback_worker(*args):
+    """The RCCL loopback checks run in a fresh, torch-free process (tests/_loopback_worker.py): an
+    earlier test of THIS process imports torch, whose bundled RCCL 2.26.6 the library would then bind,
+    and that copy cannot capture the exchange -- the tests would silently exercise the eager path."""
+    env = {k: v for k, v in os.environ.items() if k not in ("VOF2D_RCCL", "VOF2D_XCHG_GRAPH")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_loopback_worker.py")] + [str(a) for a in args],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_native_rccl_exchange_loopback():
     """vof_comm_init / vof_comm_exchange / vof_step_exchange on one GPU with both neighbours looped
-    back to the calling rank: each halo must receive the W owned rows next to it (RCCL pairs the k-th
-    send to a peer with the k-th receive from it) -- checks row ranges, byte counts, the F buffer
-    swap and the stream ordering of the in-library exchange."""
-    from vof2d import _abi
-    from vof2d.engine import Engine, make_desc, comm_unique_id, VofError
-    nx, ny, W = 160, 96, _abi.halo_rows(10)
-    own = (41, 120)
-    rows = (own[0] - W, own[1] + W)
-    e = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
-    e.set_init_F(1)
-    with pytest.raises(VofError):
-        e.step_exchange(1)                      # no communicator yet
-    uid = comm_unique_id(hip_api)
-    assert len(uid) == _abi.VOF_COMM_ID_BYTES
-    with pytest.raises(VofError):
-        e.comm_init(uid, 0, 1)                  # an interior strip cannot be rank 0 of 1
-    e.comm_init(uid, 0, 1, loopback=True)
-    rng = np.random.default_rng(5)
-    for f in ("F", "u", "v", "p"):
-        e.set(f, rng.random((rows[1] - rows[0] + 1, ny + 2)), rows)
-    before = {f: e.get(f, rows) for f in ("F", "u", "v", "p")}
-    e.comm_exchange(_abi.VOF_XCHG_F | _abi.VOF_XCHG_P)
-    e.sync()
-    lo, hi = own[0] - rows[0], own[1] - rows[0]    # array indices of own_lo / own_hi
-    for f in ("F", "u", "v", "p"):
-        got, was = e.get(f, rows), before[f]
-        if f in ("F", "p"):
-            assert np.array_equal(got[lo - W:lo], was[lo:lo + W]), f
-            assert np.array_equal(got[hi + 1:hi + 1 + W], was[hi - W + 1:hi + 1]), f
-            assert np.array_equal(got[lo:hi + 1], was[lo:hi + 1]), f
-        else:
-            assert np.array_equal(got, was), f
-    # the stepping loop: same result as the phases with a loopback copy after each, done by hand
-    ref = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
-    for f in ("F", "u", "v", "p"):
-        ref.set(f, e.get(f, rows), rows)
-    ref.istep = e.istep
-
-    def loop(fields):
-        for f in fields:
-            a = ref.get(f, rows)
-            a[lo - W:lo] = a[lo:lo + W]
-            a[hi + 1:hi + 1 + W] = a[hi - W + 1:hi + 1]
-            ref.set(f, a, rows)
-
-    # non-overlapped: deterministic, equal to the hand-made copies on every stored row.  The first
-    # step of a communicator is launched eagerly, later ones replay one captured graph per parity.
-    e.step_exchange(5, 0)
-    for _ in range(5):
-        for ph in (0, 1, 2):
-            ref.step_phase(ph)
-        loop(("F", "u", "v", "p"))
-    for f in ("F", "u", "v", "p"):
-        assert np.array_equal(e.get(f, rows), ref.get(f, rows), equal_nan=True), f
-    # overlapped: with a looped-back neighbour the halos change *value* under the running kernels
-    # (between real neighbours they are rewritten with identical values), so rows near the edges
-    # depend on timing here.  Deterministic and checked: every halo ends up holding the final
-    # owned rows next to it, and rows deeper than one step's dependency cone equal the reference.
-    for mode in (1, 2, 3, 1, 2, 3, 2, 1, 4, 4, 4, 1, 4, 4, 2, 4, 3, 4):   # 4: fused transport, one F / twin swap per step
-        for f in ("F", "u", "v", "p"):
-            ref.set(f, e.get(f, rows), rows)
-        ref.istep = e.istep
-        e.step_exchange(1, mode)
-        if mode == 4:   # all four fields together once the edge bands of the fused transport exist
-            ref.step_phase(0); ref.step_phase(1); ref.step_phase(2); loop(("p", "u", "v", "F"))
-        else:
-            ref.step_phase(0); loop(("p",)); ref.step_phase(1); loop(("u", "v")); ref.step_phase(2); loop(("F",))
-        for f in ("F", "u", "v", "p"):
-            got = e.get(f, rows)
-            assert np.array_equal(got[lo - W:lo], got[lo:lo + W], equal_nan=True), (f, mode)
-            assert np.array_equal(got[hi + 1:hi + 1 + W], got[hi - W + 1:hi + 1], equal_nan=True), (f, mode)
-            assert np.array_equal(got[lo + W:hi + 1 - W], ref.get(f, rows)[lo + W:hi + 1 - W], equal_nan=True), (f, mode)
-    # one captured graph per (parity, mode) where this process's RCCL can be captured (2.27.7+; a
-    # PyTorch-bundled 2.26.6 loaded earlier in the process runs the same steps eagerly)
-    version, graphs = e.comm_info()
-    assert version >= 22000
-    assert (e.get_counter("exchange_graph_steps") > 0) == bool(graphs)
-    e.comm_destroy()
-    e.close(); ref.close()
+    back to the calling rank, all five overlap modes, eager first step and captured graphs."""
+    _loopback_worker("modes")
 
 
 @pytest.mark.parametrize("own", [(41, 120), (1, 80), (81, 160), (70, 95)])
-def test_exchange_mode4_equals_phases_plus_copies(hip_api, own):
-    """vof_step_exchange overlap 4 (fused transport on the edge bands, one send/recv group, fused
-    transport on the other rows) on an interior strip, on the strips next to the left / right wall (one
-    band only) and on a strip so thin that its bands meet, neighbours looped back.  Nothing the second transport launch reads is being
-    received meanwhile, so -- unlike modes 1-3 on a loopback -- the result is deterministic and must
-    equal the phased step followed by hand-made halo copies on every stored row, ghost cells included."""
-    from vof2d import _abi
-    from vof2d.engine import Engine, make_desc, comm_unique_id
-    nx, ny, W = 160, 96, _abi.halo_rows(10)
-    rows = (max(0, own[0] - W), min(nx + 1, own[1] + W))
-    wall_lo, wall_hi = own[0] == 1, own[1] == nx
-    e = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
-    ref = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
-    for x in (e, ref):
-        x.set_init_F(3)
-    e.comm_init(comm_unique_id(hip_api), 0, 1, loopback=True)
-    lo, hi = own[0] - rows[0], own[1] - rows[0]
-
-    def loop(fields):
-        for f in fields:
-            a = ref.get(f, rows)
-            if not wall_lo:
-                a[lo - W:lo] = a[lo:lo + W]
-            if not wall_hi:
-                a[hi + 1:hi + 1 + W] = a[hi - W + 1:hi + 1]
-            ref.set(f, a, rows)
-
-    for n in (1, 1, 3, 2):   # the first step of a communicator is eager (and runs as mode 1), later ones are captured
-        if e.istep == 0:
-            e.step_exchange(1, 0); ref_modes = 1
-        else:
-            e.step_exchange(n, 4); ref_modes = n
-        for _ in range(ref_modes):
-            for ph in (0, 1, 2):
-                ref.step_phase(ph)
-            loop(("p", "u", "v", "F"))
-        # (if an earlier test of this process imported torch, its bundled RCCL 2.26.6 is the copy the
-        # library finds; that one cannot be captured, mode 4 then runs as eager mode 1, whose
-        # transfers overlap kernels that read the halos: only rows deeper than one step's
-        # dependency cone, and the halos' final contents, are deterministic on a loopback)
-        captured = bool(e.comm_info()[1])
-        for f in ("F", "u", "v", "p"):
-            got, want = e.get(f, rows), ref.get(f, rows)
-            if captured:
-                assert np.array_equal(got, want, equal_nan=True), (own, f, int(e.istep), np.argwhere(got != want)[:4])
-            else:
-                a0, a1 = (lo if wall_lo else lo + W), (hi + 1 if wall_hi else hi + 1 - W)
-                assert np.array_equal(got[a0:a1], want[a0:a1], equal_nan=True), (own, f, int(e.istep))
-        if not captured:   # keep the two engines identical for the next round
-            for f in ("F", "u", "v", "p"):
-                ref.set(f, e.get(f, rows), rows)
-    e.comm_destroy(); e.close(); ref.close()
+def test_exchange_mode4_equals_phases_plus_copies(own):
+    """vof_step_exchange overlap 4 -- the default of bench.py --gpus N -- replayed from the captured
+    graph, on an interior strip, next to either wall and on a strip whose bands meet."""
+    _loopback_worker("mode4", own[0], own[1])
