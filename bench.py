@@ -420,7 +420,7 @@ def residual_solve_1024(api, local, dtype="f64", tol=1e-6, cap=3000000, every=50
             "sweeps_per_s": it / (ms * 1e-3), "us_per_sweep": 1e3 * ms / max(it, 1),
             "algorithmic_GBs_24B_rule": 3 * esz * n * n * it / (ms * 1e-3) / 1e9,
             "note": "1024^2 (3 x 8.4 MB) sits in L2 / MALL: cache bandwidth, not HBM; the relative residual of this "
-                    "pure-Neumann iteration tends to 1/k (the null-space constant), so 1e-6 takes ~1e6 sweeps on any grid"}
+                    "pure-Neumann iteration decays like 1/k once the null-space constant dominates the update (1e5..1e6 sweeps for 1e-6 on any grid)"}
 
 
 def single_gpu_reference(api, n, dtype, ic, local, jacobi_iters, dt, steps=12):

@@ -145,6 +145,9 @@ struct vof2d_ctx {
   int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
   int tb_general = 0;   // force the general (dx != dy) fused Jacobi kernel
   int tb_narrow = 0;    // 1: the one-column-per-lane fused Jacobi kernel on thin, wide strips (see jacobi_tb)
+  int tb_adapt = 1;     // fused steps: shorter chunks on the tile columns the tiny-value front is crossing (k_jacobi_tb)
+  unsigned long long* d_tbmask = nullptr;  // work plan of k_jacobi_tb (TbPlan): 2 x TB_BANDS mask words, then the plan (1 + waves entries)
+  long tbplan_cap = 0;                     // waves the plan area holds
   int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = heuristic, at most 16)
   int fctx_corr_rows = 0;  // ... of its update_uv-carrying form (0 = same rule)
   int fuse_momentum = 1;
@@ -295,6 +298,7 @@ inline unsigned blocks_for(const vof2d_ctx* h, int ntiles, int R) {
 }
 
 // ------------------------------------------------------------------ launches
+constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe
 enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
                 kRhs, kOther, kTransport, NKERNELS };
 const char* const kKernelNames[NKERNELS] = {"k_momentum", "k_set_bc", "k_jacobi", "k_jacobi_tb", "k_correct",
@@ -365,7 +369,7 @@ struct L {
            (const T*)F_<T>(h, fRHO), (const T*)F_<T>(h, fNU), F_<T>(h, fUS), F_<T>(h, fVS), R);
   }
   // fused normals + kappa + predictor + rhs (vof_step only)
-  static void momentum(vof2d_ctx* h, bool virt = false) {
+  static void momentum(vof2d_ctx* h, bool virt = false, int adapt_par = -1) {
     constexpr int Wt = 64 * V, Ht = ((2 + V - 1) / V) * V, ST = Wt - 2 * Ht;
     const int ntt = (h->g.ny + ST - 1) / ST;
     // one residency round while that keeps the chunks short (strips, small grids); on large grids
@@ -373,9 +377,10 @@ struct L {
     // 665 vs 758 us) -- the halo rows of adjacent, simultaneously resident chunks are L2 hits
     int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, resident_waves(h, k_momentum<T, V>), 4, 64);
     if (h->mom_rows <= 0 && R > 32) R = 14;
-    launch(h, kMomentum, k_momentum<T, V>, dim3(blocks_for(h, ntt, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+    const TbPlan tp = tb_plan(h, adapt_par);   // (one extra block: the planner wave)
+    launch(h, kMomentum, k_momentum<T, V>, dim3(blocks_for(h, ntt, R) + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
            (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
-           virt ? 1 : 0);
+           virt ? 1 : 0, tp);
   }
   template <bool STORED>
   static void rhs(vof2d_ctx* h) {
@@ -399,15 +404,33 @@ struct L {
     const long cap = sq ? resident_waves(h, k_jacobi_tb<T, VV, TS, true, false>) : resident_waves(h, k_jacobi_tb<T, VV, TS, false, false>);
     return h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
   }
+  // the work plan of the step's five-sweep launches (see tb_make_plan): active on parity-keyed step
+  // sequences (adapt_par = istep & 1), square or not, two columns per lane, up to 64 tile columns
+  static TbPlan tb_plan(vof2d_ctx* h, int adapt_par) {
+    TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
+    if (adapt_par < 0 || !h->tb_adapt || h->tb < 5 || h->tb_narrow == 2 || h->tb_rows > 0) return tp;
+    const Consts<T> cc = C(h);
+    const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;
+    int ntt = 0;
+    const int R = jacobi_tb_plan<5, V>(h, sq, ntt);
+    const long waves = (long)blocks_for(h, ntt, R) * 4;
+    if (ntt > 64 || waves > kTbPlanWaves || (R < 32 && ntt >= 48 && h->tb_narrow != 0)) return tp;
+    tp.masks = h->d_tbmask;
+    tp.plan = h->d_tbmask + 2 * TB_BANDS;
+    tp.ntt = ntt; tp.R = R; tp.waves = (int)waves; tp.par = adapt_par;
+    return tp;
+  }
   template <int TS, int VV>
-  static void jacobi_tb_launch(vof2d_ctx* h, const Consts<T>& cc, bool sq, int src, int dst, int R, int ntt) {
+  static void jacobi_tb_launch(vof2d_ctx* h, const Consts<T>& cc, bool sq, int src, int dst, int R, int ntt, int adapt_par = -1) {
     unsigned long long* none = nullptr;
+    TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
+    if constexpr (TS == 5 && VV == V) tp = tb_plan(h, adapt_par);
     if (sq)
       launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none);
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
     else
       launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, false, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none);
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
   }
   // TS sweeps src -> dst, the last of which also reduces max|p_new - p| and max|p_new| over the owned
   // rows into d_courant[1..2] (the residual-terminated solve): same values as
@@ -422,15 +445,16 @@ struct L {
     const int ntt = (h->g.ny + ST - 1) / ST;
     const long cap = sq ? resident_waves(h, k_jacobi_tb<T, V, TS, true, true>) : resident_waves(h, k_jacobi_tb<T, V, TS, false, true>);
     const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
+    const TbPlan notp{nullptr, nullptr, 0, 0, 0, 0};   // uniform layout
     if (sq)
       launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, true, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1);
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1, notp);
     else
       launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, false, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1);
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1, notp);
   }
   template <int TS>
-  static void jacobi_tb(vof2d_ctx* h, int src, int dst) {
+  static void jacobi_tb(vof2d_ctx* h, int src, int dst, int adapt_par = -1) {
     const Consts<T> cc = C(h);
     const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;  // square cells: the product-carrying pipeline
     int ntt = 0;
@@ -450,7 +474,7 @@ struct L {
         return;
       }
     }
-    jacobi_tb_launch<TS, V>(h, cc, sq, src, dst, R, ntt);
+    jacobi_tb_launch<TS, V>(h, cc, sq, src, dst, R, ntt, adapt_par);
   }
   template <bool STORED>
   static void correct(vof2d_ctx* h) {
@@ -587,8 +611,9 @@ void copy_interior(vof2d_ctx* h, int src, int dst) {
 // into launches of h->tb fused sweeps (k_jacobi_tb); the remainder and the residual variant use the
 // single-sweep kernel.
 template <typename T>
-void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
+void jacobi_n(vof2d_ctx* h, int n, bool resid_last, int adapt_par = -1) {
   if (n <= 0) return;
+  if (!(h->tb_adapt && h->tb >= 5 && !resid_last)) adapt_par = -1;
   int cur = fP, oth = fPT;
   auto flip = [&]() { int t = cur; cur = oth; oth = t; };
   int left = n;
@@ -598,7 +623,7 @@ void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
   const int last = !resid_last ? 0 : ((tb >= 5 && n >= 5) ? 5 : ((tb >= 2 && n >= 2) ? 2 : 1));
   left -= last;
   while (left > 0) {
-    if (tb >= 5 && left >= 5) { L<T>::template jacobi_tb<5>(h, cur, oth); left -= 5; }
+    if (tb >= 5 && left >= 5) { L<T>::template jacobi_tb<5>(h, cur, oth, adapt_par); left -= 5; }
     else if (tb >= 2 && left >= 2) { L<T>::template jacobi_tb<2>(h, cur, oth); left -= 2; }
     else { L<T>::template jacobi<false>(h, cur, oth); left -= 1; }
     flip();
@@ -637,7 +662,8 @@ void jacobi_n(vof2d_ctx* h, int n, bool resid_last) {
 // 0) or zero stencil coefficients, and the first sweep itself stores the wall-face zeros of u, v
 // the second sweep reads.
 template <typename T>
-void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false, bool lean = false, bool virt = false) {
+void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false, bool lean = false, bool virt = false,
+                   int adapt_par = -1 /* istep & 1 when the caller's launch sequence is keyed by the step parity */) {
   const bool y_first = (istep % 2 == 0);    // :526, :312-318
   const bool corr = h->fuse_correct != 0;
   if (lean && !(corr && h->fuse_momentum)) lean = false;
@@ -645,14 +671,14 @@ void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false
     // cal_nu_rho (:513) is folded into its consumers: rho/nu = f(F[i,j]) recomputed per cell
     if (h->fuse_momentum) {
       // :514, :517 and the (sweep-invariant, BC-independent) rhs of :239-241 in one pass
-      L<T>::momentum(h, virt);              // virt: the previous step's set_BC launch was left out (see enqueue_step)
+      L<T>::momentum(h, virt, adapt_par);   // virt: the previous step's set_BC launch was left out (see enqueue_step)
     } else {
       L<T>::normals(h);                     // :514 loop 1
       L<T>::kappa(h);                       // :514 loop 2
       L<T>::template predictor<false>(h);   // :517
       L<T>::template rhs<false>(h);         // :521-522, rhs part (iteration invariant)
     }
-    jacobi_n<T>(h, h->d.jacobi_iters, false);  // :521-522
+    jacobi_n<T>(h, h->d.jacobi_iters, false, h->fuse_momentum ? adapt_par : -1);  // :521-522
     if (!lean) L<T>::template set_bc<BC_P | BC_F>(h);  // p part of :525 / :528; F part of :518 (first step)
   } else if (phase == 1) {
     if (corr) {                             // :524 inside the first sweep of :526
@@ -688,14 +714,14 @@ void enqueue_step(vof2d_ctx* h, int64_t istep, bool lean = false, bool virt = fa
     // wall velocity is zero, update_uv overwrites what p's ghosts would enter, the Jacobi stencil
     // multiplies them by zero coefficients), and that kernel forms them from the interior cells
     // itself.  Whoever else looks at the fields goes through settle_ghosts first.
-    L<T>::momentum(h, virt);
-    jacobi_n<T>(h, h->d.jacobi_iters, false);
+    L<T>::momentum(h, virt, (int)(istep & 1));
+    jacobi_n<T>(h, h->d.jacobi_iters, false, (int)(istep & 1));
     if (istep % 2 == 0) L<T>::template transport<true>(h); else L<T>::template transport<false>(h);
     swap_F(h);
     if (!virt) L<T>::template set_bc<BC_ALL>(h);
     return;
   }
-  for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep, full, lean);
+  for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep, full, lean, false, (int)(istep & 1));
   if (lean) L<T>::template set_bc<BC_ALL>(h);   // :518, :525, :528 in one launch
 }
 
@@ -962,6 +988,8 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
     h->f_home = h->fld[fF];
     if (hipMalloc(reinterpret_cast<void**>(&h->d_courant), 4 * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
     if (hipMemsetAsync(h->d_courant, 0, 4 * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_tbmask), (2 * TB_BANDS + 1 + kTbPlanWaves) * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
+    if (hipMemsetAsync(h->d_tbmask, 0, (2 * TB_BANDS + 1 + kTbPlanWaves) * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
   } while (0);
@@ -985,6 +1013,7 @@ int vof_destroy(vof2d_handle h) {
   comm_teardown(h);
   if (h->vis) (void)hipFree(h->vis);
   if (h->d_courant) (void)hipFree(h->d_courant);
+  if (h->d_tbmask) (void)hipFree(h->d_tbmask);
   if (h->arena) (void)hipFree(h->arena);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1394,8 +1423,9 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
   if (!strcmp(name, "jacobi_tb") || !strcmp(name, "jacobi_tb_rows") || !strcmp(name, "momentum_rows") ||
       !strcmp(name, "fuse_momentum") || !strcmp(name, "fuse_correct") || !strcmp(name, "fuse_transport") ||
       !strcmp(name, "virtual_ghosts") || !strcmp(name, "band_rows") || !strcmp(name, "fctx_rows") ||
-      !strcmp(name, "fctx_corr_rows") || !strcmp(name, "jacobi_tb_narrow")) {  // tuning knobs
+      !strcmp(name, "fctx_corr_rows") || !strcmp(name, "jacobi_tb_narrow") || !strcmp(name, "jacobi_tb_adapt")) {  // tuning knobs
     if (!strcmp(name, "jacobi_tb")) h->tb = (int)value;
+    else if (!strcmp(name, "jacobi_tb_adapt")) h->tb_adapt = (int)value;
     else if (!strcmp(name, "fctx_rows")) h->fctx_rows = (int)value;
     else if (!strcmp(name, "fctx_corr_rows")) h->fctx_corr_rows = (int)value;
     else if (!strcmp(name, "jacobi_tb_narrow")) h->tb_narrow = (int)value;
@@ -1430,6 +1460,7 @@ int vof_get_param(vof2d_handle h, const char* name, double* value) {
   if (!strcmp(name, "pitch")) { *value = (double)h->g.pitch; return VOF_OK; }
   if (!strcmp(name, "rows_per_wave")) { *value = (double)pick_rows(h, h->g.ntj); return VOF_OK; }
   if (!strcmp(name, "jacobi_tb")) { *value = (double)h->tb; return VOF_OK; }
+  if (!strcmp(name, "jacobi_tb_adapt")) { *value = (double)h->tb_adapt; return VOF_OK; }
   if (!strcmp(name, "fuse_transport")) {  // 1 if vof_step runs both FCT sweeps as one kernel on this handle
     *value = (h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->fuse_correct && h->fuse_momentum) ? 1.0 : 0.0;
     return VOF_OK;
@@ -1662,7 +1693,7 @@ int enqueue_step_exchange(vof2d_ctx* h, int mode) {
   // columns and the next step's k_momentum forms the ones it reads, for owned and received rows alike.
   const bool lean = h->fuse_correct && h->fuse_momentum;
   const bool virt = lean && h->virtual_ghosts;
-  enqueue_phase<T>(h, 0, h->istep, false, lean, virt);
+  enqueue_phase<T>(h, 0, h->istep, false, lean, virt, (int)(h->istep & 1));
   if (mode == 4) {
     // fused transport (update_uv + both sweeps in one pass), edge bands first: p, u, v and F (from
     // the twin buffer) leave as soon as the bands exist and travel under the transport of the

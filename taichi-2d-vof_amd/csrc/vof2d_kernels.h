@@ -236,7 +236,8 @@ __device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
 // full routine.  With a branch per quotient the compiler cannot overlap the dependent fma chains
 // of a lane's V cells.
 template <typename T, int V, bool SMALL_B = false>
-__device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], const T (&b)[V], const T (&y)[V]) {
+__device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], const T (&b)[V], const T (&y)[V],
+                                               int* cold = nullptr /* set to 1 when the tiny / huge tier ran */) {
   bool odd = false;
 #pragma unroll
   for (int q = 0; q < V; ++q) {
@@ -257,6 +258,7 @@ __device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], con
     if (nonzero) {
 #pragma unroll
       for (int q = 0; q < V; ++q) res[q] = div_by_const<T, SMALL_B>(a[q], b[q], y[q]);
+      if (cold) *cold = 1;
     }
   }
 }
@@ -642,6 +644,130 @@ __global__ __launch_bounds__(256) void k_predictor(Geom g, Consts<T> c, const T*
   }
 }
 
+// ------------------------------------------------------------------ work plan of k_jacobi_tb
+// While the decaying front of the pressure iteration crosses the grid, the waves of k_jacobi_tb
+// whose rows lie in the band of tiny values (1e-280 ... 4.9e-324) execute about twice the
+// instructions per row (the exact division's scaled tier), and with one residency round per launch
+// they run on alone after the others have ended: 145 us per launch instead of 92 (4096^2).  The
+// launches therefore report WHERE the tier ran -- one bit per (row band, tile column) -- and the next
+// step cuts every tile column into chunks of equal COST instead of equal length: the same number of
+// waves, short chunks inside the band, slightly longer ones elsewhere, so that all waves end
+// together again.  Which rows a wave takes never changes a value (every cell is computed from the
+// same operands whatever the chunking; the parity tests run with the plan active).
+//   TbPlan::masks  two sets of TB_BANDS words, bit j = tile column j: a step reads set (istep & 1)
+//                  -- what the previous step's launches reported -- and reports into the other, which
+//                  this step's planner clears first (its last readers were the previous step's launches)
+//   TbPlan::plan   [0] = 1 if a plan is active (else the uniform layout), [1 + wave] = the wave's
+//                  tile column and rows, packed (plan_pack)
+// The planner is one extra wave of k_momentum's launch (the kernel in front of the Jacobi launches
+// in the fused step): it runs beside the other waves, off the critical path.
+constexpr int TB_BANDS = 64;          // row bands of the hit masks
+constexpr int TB_SLOW10 = 20;         // cost of a band row in tenths of an ordinary row
+struct TbPlan {
+  unsigned long long* masks;          // nullptr: no plan (uniform layout)
+  unsigned long long* plan;
+  int ntt, R, waves, par;             // tile columns (<= 64), uniform chunk length, waves of a launch, istep & 1
+};
+__device__ __forceinline__ unsigned long long plan_pack(int tj, int ra, int rb) {
+  return (unsigned long long)(unsigned)tj | ((unsigned long long)(unsigned)ra << 8) | ((unsigned long long)(unsigned)rb << 36);
+}
+__device__ __forceinline__ int tb_band_of(const Geom& g, int i) {   // row -> band index
+  const int rows = g.ihi - g.ilo + 1, h = (rows + TB_BANDS - 1) / TB_BANDS;
+  return (i - g.ilo) / h;
+}
+// One block of 256 threads (the planner block of k_momentum's launch; it must not outlast the
+// launch's other waves, so the per-chunk work is spread over all its threads).  32-bit integers.
+struct TbPlanShared {
+  unsigned prefix[64][TB_BANDS + 1];   // prefix[j][b] = cost of rows [0, b * bh) of tile column j, in tenths of a row
+  unsigned long long band[TB_BANDS];   // the reported (band, column) bits
+  int first[65];                       // first wave of column j; first[ntt] = planned waves
+  int n[64];                           // chunks of column j
+};
+// row position (0 .. rows) where the cumulative cost of column j reaches T
+__device__ __forceinline__ int tb_pos(const TbPlanShared& sh, int j, unsigned T, int rows, int bh) {
+  int lo = 0, hi = TB_BANDS;           // largest b with prefix[j][b] <= T
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (sh.prefix[j][mid] <= T) lo = mid; else hi = mid;
+  }
+  const bool slow = ((sh.band[lo] >> j) & 1ull) != 0ull;
+  const unsigned rest = T - sh.prefix[j][lo];
+  int pos = lo * bh + (int)(slow ? rest / (unsigned)TB_SLOW10 : rest / 10u);
+  const int bend = (lo + 1) * bh;
+  if (pos > bend) pos = bend;
+  return pos < rows ? pos : rows;
+}
+__device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) {
+  const int t = threadIdx.x, lane = t & 63;
+  const unsigned long long* rd = tp.masks + (size_t)tp.par * TB_BANDS;
+  unsigned long long* wr = tp.masks + (size_t)(tp.par ^ 1) * TB_BANDS;
+  const int rows = g.ihi - g.ilo + 1, bh = (rows + TB_BANDS - 1) / TB_BANDS;
+  const unsigned long long mine = rd[lane];     // band `lane` (nobody writes the read set during this step)
+  const bool any = __any(mine != 0ull);         // (the same in all four waves)
+  if (t < 64) {
+    wr[lane] = 0ull;                            // this step's launches report into the other set
+    sh.band[lane] = mine;
+    if (lane == 0) tp.plan[0] = any ? 1ull : 0ull;
+  }
+  if (!any) return;                             // block-uniform
+  __syncthreads();
+  if (t < 64) {   // wave 0: per column, the cost prefix over the bands and the number of chunks
+    const int j = lane;
+    unsigned cost = 0;
+    for (int b = 0; b < TB_BANDS; ++b) {
+      sh.prefix[j][b] = cost;
+      const int r0 = b * bh, r1 = r0 + bh < rows ? r0 + bh : rows;
+      if (r1 > r0) cost += (unsigned)(r1 - r0) * (((sh.band[b] >> j) & 1ull) ? (unsigned)TB_SLOW10 : 10u);
+    }
+    sh.prefix[j][TB_BANDS] = cost;
+    if (j >= tp.ntt) cost = 0;
+    unsigned total = cost;
+    for (int sft = 32; sft > 0; sft >>= 1) total += __shfl_xor(total, sft, 64);
+    // chunks per column, proportional to its cost (at least one), within the waves of a launch
+    const int nmax = rows >= 4 ? rows / 4 : 1;
+    int n = j < tp.ntt ? (int)(((unsigned long long)cost * (unsigned)tp.waves) / total) : 0;
+    if (j < tp.ntt && n < 1) n = 1;
+    if (n > nmax) n = nmax;
+    int sum = n;
+    for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
+    // (the floor leaves a few waves over: one more for the first columns; never more than `waves`)
+    if (sum < tp.waves && j < tp.ntt && j < tp.waves - sum && n < nmax) n += 1;
+    for (int guard = 0; guard < 4096; ++guard) {   // the at-least-one rule can overshoot on tiny grids: trim the largest
+      sum = n;
+      for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
+      if (sum <= tp.waves) break;
+      int mx = n;
+      for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(mx, sft, 64); mx = o > mx ? o : mx; }
+      const unsigned long long who = __ballot(n == mx);
+      if (lane == __ffsll((long long)who) - 1) n -= 1;
+    }
+    int first = n;   // inclusive prefix sum -> the column's first wave
+    for (int sft = 1; sft < 64; sft <<= 1) { const int o = __shfl_up(first, sft, 64); if (lane >= sft) first += o; }
+    sh.n[j] = n;
+    sh.first[j] = first - n;
+    if (lane == 63) sh.first[64] = first;
+  }
+  __syncthreads();
+  const int planned = sh.first[64];
+  for (int w = t; w < tp.waves; w += 256) {
+    unsigned long long e = plan_pack(0, 1, 0);   // waves past the planned ones: empty
+    if (w < planned) {
+      int lo = 0, hi = 64;                       // the column of wave w: largest j with first[j] <= w
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sh.first[mid] <= w) lo = mid; else hi = mid;
+      }
+      const int j = lo, n = sh.n[j], k = w - sh.first[j];
+      // chunk k of column j: between the rows where the cumulative cost reaches k / n and (k + 1) / n of the column's
+      const unsigned cost = sh.prefix[j][TB_BANDS];
+      const int a = k == 0 ? 0 : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)k) / (unsigned)n), rows, bh);
+      const int b = k == n - 1 ? rows : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)(k + 1)) / (unsigned)n), rows, bh);
+      e = plan_pack(j, g.ilo + a, g.ilo + b - 1);   // (b == a: an empty chunk, the wave returns at once)
+    }
+    tp.plan[1 + w] = e;
+  }
+}
+
 // ------------------------------------------------------------------ fused momentum + rhs
 // get_normal_young (2dvof.py:283-309) + advect_upwind (:206-233) + the rhs of solve_p_jacobi
 // (:239-241) in one pass: F, u, v -> u*, v*, rhs (6 array passes instead of 16).  mx, my and kappa
@@ -720,7 +846,13 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* __restrict__ F,
                                                    const T* __restrict__ u, const T* __restrict__ v,
                                                    T* __restrict__ us, T* __restrict__ vs, T* __restrict__ rhs,
-                                                   int R, int ntt, int virt) {
+                                                   int R, int ntt, int virt, TbPlan tp) {
+  // the launch's last block is the planner of this step's k_jacobi_tb launches (see tb_make_plan)
+  if (tp.masks != nullptr && blockIdx.x == gridDim.x - 1) {
+    __shared__ TbPlanShared plan_sh;
+    tb_make_plan(g, tp, plan_sh);
+    return;
+  }
   // virt (full-domain fused steps, DESIGN.md "virtual ghosts"): the previous step did not run
   // set_BC; the ghost cells this kernel reads -- F's ghost rows and columns, v's ghost rows, u's
   // ghost columns -- are formed from the interior cells set_BC would have copied (:164-189).
@@ -1071,7 +1203,8 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
 template <typename T, int V, int TS, bool SQ, bool RESID = false>
 __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
                                                     const T* __restrict__ rhs, T* __restrict__ pn, int R,
-                                                    int ntt, unsigned long long* __restrict__ norm_bits = nullptr) {
+                                                    int ntt, unsigned long long* __restrict__ norm_bits = nullptr,
+                                                    TbPlan tp = TbPlan{nullptr, nullptr, 0, 0, 0, 0}) {
   // SQ (dxi2 == dyi2 bitwise, i.e. square cells): the stencil has ONE off-diagonal coefficient, so
   // the product coef * p[i,j] is the same number in the equations of all four neighbours of (i,j).
   // Stages 2.. then receive products instead of values -- 1 multiply per cell-sweep instead of 4
@@ -1088,16 +1221,33 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
   constexpr int STRIDE = W - 2 * H;
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int tj = wave % ntt, ch = wave / ntt;
+  // wave -> (tile column tj, rows [ra, rb]): chunks of R rows of every column, or, while the tiny-value
+  // front crosses the grid, the equal-cost chunks of the step's plan (tb_make_plan)
+  int tj = wave % ntt, ra = g.ilo + (wave / ntt) * R, rb = ra + R - 1;
+  bool planned = false;
+  if (tp.masks != nullptr) {
+    const unsigned long long* pl = tp.plan;
+    if (pl[0] != 0ull) {
+      const unsigned long long e = pl[1 + wave];    // scalar loads: nobody writes the plan during the launch
+      tj = (int)(e & 0xffull);
+      ra = (int)((e >> 8) & 0xfffffffull);
+      rb = (int)((e >> 36) & 0xfffffffull);
+      planned = true;
+    }
+  }
+  tj = __builtin_amdgcn_readfirstlane(tj);
+  ra = __builtin_amdgcn_readfirstlane(ra);
+  rb = __builtin_amdgcn_readfirstlane(rb);
+  if (planned && rb < ra) return;   // an unused wave of the plan
   const int c0 = 1 - H + tj * STRIDE;
   const int j0 = c0 + lane * V;
-  const int ra = g.ilo + ch * R;
   if (ra > g.ihi) return;  // wave-uniform
-  const int rb = ra + R - 1 < g.ihi ? ra + R - 1 : g.ihi;
+  if (rb > g.ihi) rb = g.ihi;
   const int nx = g.nx, ny = g.ny;
   const int jlo = c0 + H > 1 ? c0 + H : 1;
   const int jhi = c0 + W - H - 1 < ny ? c0 + W - H - 1 : ny;
   const int64_t pitch = g.pitch;
+  int hit = 0;   // this lane ran the tiny-numerator tier (adaptive layout: reported per tile column)
 
   T an[V], as_[V], apI[V], yI[V];
 #pragma unroll
@@ -1209,7 +1359,7 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
           carry[q] = o;
         }
       } else {
-        div_by_const_v<T, V>(carry, num, apI, yI);
+        div_by_const_v<T, V>(carry, num, apI, yI, &hit);
       }
       if constexpr (RESID) {
         if (SQ && s == TS - 1) {
@@ -1255,6 +1405,10 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
     sub(IC<5>{}, t + 5);
   }
   if constexpr (RESID) norm_publish<T>(upd, pmx, norm_bits);
+  if (tp.masks != nullptr && __any(hit != 0) && lane == 0) {   // report the (row band, tile column) cells of this chunk
+    unsigned long long* wr = tp.masks + (size_t)(tp.par ^ 1) * TB_BANDS;
+    for (int b = tb_band_of(g, ra); b <= tb_band_of(g, rb); ++b) atomicOr(wr + b, 1ull << tj);
+  }
 }
 
 // ------------------------------------------------------------------ corrector

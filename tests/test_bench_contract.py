@@ -47,7 +47,7 @@ def test_bench_default_workload_reports_the_1024_residual_solve():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
     rs = d["residual_solve_1024"]
-    assert rs["converged"] and rs["residual"] <= 1e-6 and 500000 <= rs["iterations"] < 3000000 and rs["sweeps_per_s"] > 1e4
+    assert rs["converged"] and rs["residual"] <= 1e-6 and 100000 <= rs["iterations"] < 3000000 and rs["sweeps_per_s"] > 1e4
 
 
 def test_bench_refuses_a_gpu_count_that_does_not_match_the_launcher():
@@ -80,7 +80,7 @@ def test_bench_starts_its_own_workers_when_no_launcher_did():
 
 def test_self_started_run_ends_when_a_worker_dies():
     """A worker that exits non-zero takes the launch down with its code instead of leaving the
-    others waiting (here: every worker refuses --steps -1 before touching anything)."""
+    others waiting in the rendezvous (VOF2D_BENCH_TEST_DIE_RANK: that worker exits with code 7)."""
     env = dict(_clean_env(), VOF2D_BENCH_TEST_DIE_RANK="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run"], capture_output=True,
                        text=True, timeout=120, env=env)

@@ -9,8 +9,9 @@ with the properties the iteration offers.
 Note on the relative criterion: the pressure equation is pure Neumann and its right-hand side,
 rho/dt * div(u*), does not sum to zero, so every Jacobi sweep adds the same constant to p (the
 null-space component; harmless, only grad p is used).  Once the rest of the update has decayed,
-max|p_new - p| is that constant c and max|p_new| ~ c * k: the relative residual reads 1/k and
-"1e-6" takes ~1e6 sweeps on any grid (oracle: 1 007 500 at 64^2, 964 900 at 128^2, 869 100 at 256^2).
+max|p_new - p| is that constant c and max|p_new| grows by c per sweep: the relative residual decays
+like 1/k and "1e-6" takes 1e5..1e6 sweeps whatever the grid (oracle: 1 007 500 sweeps at 64^2, 964 900
+at 128^2, 869 100 at 256^2; MI355X: 325 010 at 1024^2, 1.06 s).
 """
 import numpy as np
 import pytest
@@ -86,7 +87,8 @@ def test_oracle_diverged_field_is_not_converged(oracle_api):
     (256, 256, "f64", "rel", 1e-4, 100),      # ~1e4 sweeps, 5 per launch, norms in the last launch
     (256, 256, "f64", "abs", 2e-3, 250),
     (96, 130, "f64", "rel", 1e-3, 37),        # odd check interval: 35 fused + 2 fused (resid) sweeps per check
-    (64, 48, "f64", "abs", 1e-2, 1),          # every sweep checked: the single-sweep kernel's reduction
+    (64, 48, "f64", "abs", 6e-2, 1),          # every sweep checked: the single-sweep kernel's reduction (the
+                                              # absolute update tends to the null-space constant, 0.047 here)
     (64, 64, "f64", "rel", 1e-3, 12),         # 10 fused + 2 fused (resid) sweeps per check
     (128, 128, "f32", "rel", 1e-3, 50),
 ])
@@ -160,7 +162,7 @@ def test_baseline_config1_1024_dam_break_to_1e6(hip_api):
     assert all(x >= y for x, y in zip(hist, hist[1:])) and hist[-1] < hist[0]
     e = predictor_state(engine(hip_api, n, n, "f64", "f32", ic=1), 0)
     it, res = e.solve_p(1e-6, 3000000, 5000, "rel")
-    assert res <= 1e-6 and it % 5000 == 0 and 500000 <= it < 3000000
+    assert res <= 1e-6 and it % 5000 == 0 and 100000 <= it < 3000000
     p_a = e.get("p")
     e2 = predictor_state(engine(hip_api, n, n, "f64", "f32", ic=1), 0)
     it2, res2 = e2.solve_p(1e-6, 3000000, 1000, "rel")     # finer checks: stops within one coarse interval

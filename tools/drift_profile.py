@@ -7,11 +7,14 @@ sys.path.insert(0, os.path.join(ROOT, "taichi-2d-vof_amd"))
 ap = argparse.ArgumentParser()
 ap.add_argument("--nx", type=int, default=8192); ap.add_argument("--ny", type=int, default=8192)
 ap.add_argument("--at", default="10,200,600,1200,2000"); ap.add_argument("-ic", type=int, default=1)
+ap.add_argument("--set", default="", help="knob=value[,knob=value] tuning parameters (vof_set_param)")
 a = ap.parse_args()
 from vof2d._lib import hip_api
 from vof2d.engine import Engine, make_desc
 api = hip_api()
 e = Engine(api, make_desc(api, a.nx, a.ny, "f64", "f32", device=0))
+for kv in [x for x in a.set.split(",") if x]:
+    e.set_param(kv.split("=")[0], float(kv.split("=")[1]))
 e.set_init_F(a.ic)
 done = 0
 for tgt in [int(x) for x in a.at.split(",")]:
