@@ -12,7 +12,8 @@ Extensions (not in the reference, which hard-codes them at :9,:19-20 and loops u
     --steps N        stop after N steps   (default 0 = run until Ctrl-C, like the reference)
     --verbs          call the kernels one by one exactly as the main loop :513-528 does, instead of
                      the fused vof_step() schedule (same results, more HBM traffic)
-    --jacobi-tol T   residual-terminated pressure solve (max|p_new-p| <= T, capped by --jacobi-max)
+    --jacobi-tol T   residual-terminated pressure solve, capped by --jacobi-max sweeps;
+    --jacobi-crit    abs: max|p_new-p| <= T (default), rel: max|p_new-p| / max|p_new| <= T (vof_solve_p)
     --coord-cast     f32 | none           (keep / drop the .astype(np.float32) of :43,:45)
 """
 import argparse
@@ -33,6 +34,7 @@ parser.add_argument('--steps', type=int, default=0)
 parser.add_argument('--verbs', action='store_true')
 parser.add_argument('--jacobi-tol', type=float, default=0.0)
 parser.add_argument('--jacobi-max', type=int, default=2000)
+parser.add_argument('--jacobi-crit', choices=['abs', 'rel'], default='abs')
 parser.add_argument('--device', type=int, default=0)
 parser.add_argument('--vis', type=int, choices=[0, 1, 2, 3, 4], default=0,
                     help='what the reference GUI would display (SPACE cycles it there, 2dvof.py:508-509): '
@@ -68,7 +70,7 @@ def main():
             for _ in range(n):   # main loop :513-528 with the residual-terminated solve (extension)
                 sim.istep = sim.istep + 1
                 sim.cal_nu_rho(); sim.get_normal_young(); sim.advect_upwind(); sim.set_BC()
-                sim.eng.solve_p_residual(args.jacobi_tol, args.jacobi_max, 10)
+                sim.eng.solve_p(args.jacobi_tol, args.jacobi_max, 10, args.jacobi_crit)
                 sim.update_uv(); sim.set_BC()
                 sim.solve_VOF_rudman(sim.istep); sim.post_process_f(); sim.set_BC()
         elif args.verbs:

@@ -69,6 +69,7 @@ def parse():
                          "kills it and tries the next carrier (default 300 + 0.01 per step; three times that for torch)")
     ap.add_argument("--no-supervisor", action="store_true", help="N > 1: run in this process, no watchdog / fallback")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--fast-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true",
                     help="N > 1: start the workers, let them find each other through the rendezvous directory and "
                          "report -- no GPU work (self-test of the launcher)")
@@ -433,9 +434,58 @@ def single_gpu_reference(api, n, dtype, ic, local, jacobi_iters, dt, steps=12):
             "value": n * n * steps / el, "unit": "cell-updates/s", "ms_per_step": 1e3 * el / steps, "steps": steps}
 
 
+def fast_leg(a):
+    """Child process of the N = 1 run: the same workload on the FMA-contracted build
+    (libvof2d_hip_fast.so), and what contraction does to the results: F after 1000
+    steps of BASELINE configs[0] (128^2 dam-break fp64) against the committed fixture
+    tests/golden/dam128_f64.npz, which the parity build reproduces exactly (north-star bar: 1e-5)."""
+    import numpy as np
+    from vof2d._lib import hip_api
+    from vof2d.engine import Engine, make_desc
+    api = hip_api(fast=True)
+    nx = a.nx or 4096
+    ny = a.ny or nx
+    e = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=int(os.environ.get("LOCAL_RANK", "0")),
+                              jacobi_iters=a.jacobi_iters, dt=a.dt if a.dt > 0 else 4e-6))
+    e.set_init_F(a.ic)
+    el = timed_steps(e, a.warmup, a.steps)
+    e.close()
+    out = {"build": "hipcc -ffp-contract=fast (FMA contraction; not bit-identical to the reference's operation order)",
+           "value": nx * ny * a.steps / el, "unit": "cell-updates/s", "ms_per_step": 1e3 * el / a.steps}
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "dam128_f64.npz"))
+        g = Engine(api, make_desc(api, 128, 128, "f64", "f32", device=int(os.environ.get("LOCAL_RANK", "0"))))
+        g.set_init_F(1)
+        g.step(100)
+        d100 = float(np.max(np.abs(g.get("F") - z["F_100"])))
+        g.step(900)
+        d1000 = float(np.max(np.abs(g.get("F") - z["F_1000"])))
+        g.close()
+        out.update({"F_Linf_vs_parity_build_128x128_step_100": d100, "F_Linf_vs_parity_build_128x128_step_1000": d1000,
+                    "meets_1e-5_bar_at_step_1000": bool(d1000 <= 1e-5)})
+    except Exception as exc:
+        out["difference_error"] = str(exc)
+    print(json.dumps(out), flush=True)
+
+
+def run_fast_leg(a):
+    cmd = [sys.executable, os.path.abspath(__file__), "--fast-leg", "--steps", str(a.steps), "--warmup", str(a.warmup),
+           "--dtype", a.dtype, "-ic", str(a.ic), "--jacobi-iters", str(a.jacobi_iters)]
+    if a.nx:
+        cmd += ["--nx", str(a.nx), "--ny", str(a.ny or a.nx)]
+    if a.dt > 0:
+        cmd += ["--dt", str(a.dt)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    return json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+
+
 # --------------------------------------------------------------------------------------------------
 def main():
     a = parse()
+    if a.fast_leg:
+        return fast_leg(a)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not a.child:
         raise SystemExit(launch_workers(a))       # no launcher around us: be the launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -720,6 +770,12 @@ def main():
                 out["sustained"] = sustained_record(api, nx, ny, a.dtype, a.ic, local, a.jacobi_iters, dt, a.sustained_steps)
             except Exception as exc:
                 out["sustained"] = {"error": str(exc)}
+            try:   # what bit-faithful arithmetic costs: the same workload on the FMA-contracted build (own process)
+                out["fast_build"] = run_fast_leg(a)
+                if "value" in out["fast_build"]:
+                    out["fast_build"]["speedup_over_parity_build"] = out["fast_build"]["value"] / out["value"]
+            except Exception as exc:
+                out["fast_build"] = {"error": str(exc)}
             if not a.nx:      # default workload only
                 try:
                     out["residual_solve_1024"] = residual_solve_1024(api, local)

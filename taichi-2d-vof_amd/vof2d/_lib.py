@@ -12,21 +12,31 @@ from . import _abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "build", "libvof2d_hip.so"))
 
+FAST_LIB_PATH = LIB_PATH.replace("libvof2d_hip.so", "libvof2d_hip_fast.so")
+
 _api = None
 
 
-def hip_api():
-    """Bound `_abi.Api` of libvof2d_hip.so (loaded once)."""
+def hip_api(fast=False):
+    """Bound `_abi.Api` of libvof2d_hip.so (loaded once).
+
+    fast=True: the FMA-contracted build (libvof2d_hip_fast.so) instead -- measurement only (bench.py's
+    fast leg, tests/test_fast_build.py), its results are not the reference's.  One process loads one
+    of the two (both export the same symbols)."""
     global _api
+    path = FAST_LIB_PATH if fast else LIB_PATH
+    if _api is not None and getattr(_api, "path", path) != path:
+        raise ImportError("this process already loaded %s" % _api.path)
     if _api is None:
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(path):
             raise ImportError(
-                "libvof2d_hip.so not found at %s -- the HIP extension is not built; "
-                "run `make -C taichi-2d-vof_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
-        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+                "%s not found -- the HIP extension is not built; "
+                "run `make -C taichi-2d-vof_amd/csrc` (there is no CPU fallback)" % path)
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         api = _abi.bind(lib, "vof_")
         backend = api.backend().decode()
         if backend != "hip-gfx950":
-            raise ImportError("unexpected backend %r in %s" % (backend, LIB_PATH))
+            raise ImportError("unexpected backend %r in %s" % (backend, path))
+        api.path = path
         _api = api
     return _api

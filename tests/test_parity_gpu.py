@@ -656,3 +656,38 @@ def test_long_runs_are_deterministic(hip_api):
             assert np.array_equal(x, y, equal_nan=True), (f, int(a.istep), int((x != y).sum()))
     F = a.get("F")
     assert np.isfinite(F).all() and F.min() >= 0.0 and F.max() <= 1.0
+
+
+def test_baseline_config4_2048_bubble_fp32_full_size(hip_api):
+    """BASELINE configs[4] at full size: 2048^2 rising bubble (-ic 2), fp32, CSF surface-tension path.
+    The fp64 run of the same library (value-for-value equal to the oracle wherever the oracle can
+    follow, see the parity tests) is the mixed-precision reference; tolerances as in the miniature
+    (integral quantities): relative liquid-mass difference <= 2e-5, bubble-centroid shift
+    <= 0.05 cell, L1(F) / cells <= 2e-4.  Plus what the physics offers: 0 <= F <= 1, mass conserved to
+    1e-5 over the run, the bubble stays on the centre line and rises."""
+    n, steps = 2048, 300
+    a = engine(hip_api, n, n, "f32", "f32", ic=2)
+    b = engine(hip_api, n, n, "f64", "f32", ic=2)
+    F0 = b.get("F")[1:-1, 1:-1].copy()
+    a.step(steps); b.step(steps)
+    assert a.get_counter("courant_violations") == 0 and b.get_counter("courant_violations") == 0
+    Fa = a.get("F")[1:-1, 1:-1].astype(np.float64)
+    Fb = b.get("F")[1:-1, 1:-1]
+    for F in (Fa, Fb):
+        assert F.min() >= 0.0 and F.max() <= 1.0
+        assert abs(F.sum() - F0.sum()) / F0.sum() <= 1e-5
+    assert abs(Fa.sum() - Fb.sum()) / Fb.sum() <= 2e-5
+    x = np.arange(n) + 0.5
+
+    def centroid(F):
+        g = 1.0 - F                      # gas fraction: the bubble
+        return np.array([(g.sum(axis=1) * x).sum(), (g.sum(axis=0) * x).sum()]) / g.sum()
+
+    ca, cb, c0 = centroid(Fa), centroid(Fb), centroid(F0)
+    assert np.max(np.abs(ca - cb)) <= 0.05
+    assert np.abs(Fa - Fb).sum() / (n * n) <= 2e-4
+    assert abs(cb[0] - n / 2) <= 0.05 and abs(ca[0] - n / 2) <= 0.05     # mirror symmetry about x = Lx / 2
+    assert cb[1] > c0[1] and ca[1] > c0[1]                               # the gas moves to +y
+    # ghost cells satisfy set_BC (2dvof.py:162-189) at full size in fp32 too
+    F = a.get("F")
+    assert np.array_equal(F[:, 0], F[:, 1]) and np.array_equal(F[0, :], F[1, :]) and np.array_equal(F[-1, :], F[-2, :])
