@@ -145,6 +145,7 @@ struct vof2d_ctx {
   int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
   int tb_general = 0;   // force the general (dx != dy) fused Jacobi kernel
   int tb_narrow = 0;    // 1: the one-column-per-lane fused Jacobi kernel on thin, wide strips (see jacobi_tb)
+  int tb_wide = 0;      // fp32: four columns per lane (16-byte loads, 256-column tiles) in the fused Jacobi kernel
   int tb_adapt = 1;     // fused steps: shorter chunks on the tile columns the tiny-value front is crossing (k_jacobi_tb)
   unsigned long long* d_tbmask = nullptr;  // work plan of k_jacobi_tb (TbPlan): 2 x TB_BANDS mask words, then the plan (1 + waves entries)
   long tbplan_cap = 0;                     // waves the plan area holds
@@ -406,13 +407,16 @@ struct L {
   }
   // the work plan of the step's five-sweep launches (see tb_make_plan): active on parity-keyed step
   // sequences (adapt_par = istep & 1), square or not, two columns per lane, up to 64 tile columns
+  static int tb_cols(const vof2d_ctx* h) { return (sizeof(T) == 4 && h->tb_wide) ? 4 : V; }   // columns per lane of the fused Jacobi
   static TbPlan tb_plan(vof2d_ctx* h, int adapt_par) {
     TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
     if (adapt_par < 0 || !h->tb_adapt || h->tb < 5 || h->tb_narrow == 2 || h->tb_rows > 0) return tp;
     const Consts<T> cc = C(h);
     const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;
     int ntt = 0;
-    const int R = jacobi_tb_plan<5, V>(h, sq, ntt);
+    int R;
+    if constexpr (sizeof(T) == 4) R = tb_cols(h) == 4 ? jacobi_tb_plan<5, 4>(h, sq, ntt) : jacobi_tb_plan<5, V>(h, sq, ntt);
+    else R = jacobi_tb_plan<5, V>(h, sq, ntt);
     const long waves = (long)blocks_for(h, ntt, R) * 4;
     if (ntt > 64 || waves > kTbPlanWaves || (R < 32 && ntt >= 48 && h->tb_narrow != 0)) return tp;
     tp.masks = h->d_tbmask;
@@ -424,7 +428,7 @@ struct L {
   static void jacobi_tb_launch(vof2d_ctx* h, const Consts<T>& cc, bool sq, int src, int dst, int R, int ntt, int adapt_par = -1) {
     unsigned long long* none = nullptr;
     TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
-    if constexpr (TS == 5 && VV == V) tp = tb_plan(h, adapt_par);
+    if (TS == 5 && VV == tb_cols(h)) tp = tb_plan(h, adapt_par);
     if (sq)
       launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
              (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
@@ -471,6 +475,14 @@ struct L {
         int ntt1 = 0;
         const int R1 = jacobi_tb_plan<TS, 1>(h, sq, ntt1);
         jacobi_tb_launch<TS, 1>(h, cc, sq, src, dst, R1, ntt1);
+        return;
+      }
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (h->tb_wide && h->tb_rows <= 0) {   // fp32: 16 bytes per lane
+        int ntt4 = 0;
+        const int R4 = jacobi_tb_plan<TS, 4>(h, sq, ntt4);
+        jacobi_tb_launch<TS, 4>(h, cc, sq, src, dst, R4, ntt4, adapt_par);
         return;
       }
     }
@@ -1423,9 +1435,11 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
   if (!strcmp(name, "jacobi_tb") || !strcmp(name, "jacobi_tb_rows") || !strcmp(name, "momentum_rows") ||
       !strcmp(name, "fuse_momentum") || !strcmp(name, "fuse_correct") || !strcmp(name, "fuse_transport") ||
       !strcmp(name, "virtual_ghosts") || !strcmp(name, "band_rows") || !strcmp(name, "fctx_rows") ||
-      !strcmp(name, "fctx_corr_rows") || !strcmp(name, "jacobi_tb_narrow") || !strcmp(name, "jacobi_tb_adapt")) {  // tuning knobs
+      !strcmp(name, "fctx_corr_rows") || !strcmp(name, "jacobi_tb_narrow") || !strcmp(name, "jacobi_tb_adapt") ||
+      !strcmp(name, "jacobi_tb_wide")) {  // tuning knobs
     if (!strcmp(name, "jacobi_tb")) h->tb = (int)value;
     else if (!strcmp(name, "jacobi_tb_adapt")) h->tb_adapt = (int)value;
+    else if (!strcmp(name, "jacobi_tb_wide")) h->tb_wide = (int)value;
     else if (!strcmp(name, "fctx_rows")) h->fctx_rows = (int)value;
     else if (!strcmp(name, "fctx_corr_rows")) h->fctx_corr_rows = (int)value;
     else if (!strcmp(name, "jacobi_tb_narrow")) h->tb_narrow = (int)value;

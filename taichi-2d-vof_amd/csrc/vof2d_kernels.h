@@ -899,23 +899,25 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   const int r0 = ra - 1, r1 = rb + 3;
   load_F(F2, r0 - 2);
   load_F(F1, r0 - 1);
-  load_u(u3, r0 - 3);
-  load_u(u2, r0 - 2);
-  load_v(v3, r0 - 3);
-  load_v(v2, r0 - 2);
+  // u, v rows below ra-1 are never used by a stored value (the first stored u*, v* row is ra, which
+  // reads rows ra-1 .. ra+1; F needs ra-3 .. for the normals behind kappa): not loaded, the window
+  // starts from zeros (three row loads per array and chunk less)
+  auto zero_row = [](Row<T, V>& w) {
+    w.l = w.r = (T)0;
+#pragma unroll
+    for (int q = 0; q < V; ++q) w.c[q] = (T)0;
+  };
+  zero_row(u3); zero_row(u2); zero_row(v3); zero_row(v2);
   if (edge_cols) {
     mirror_ghost_cols<T, V>(F2, j0, ny);
     mirror_ghost_cols<T, V>(F1, j0, ny);
-    mirror_ghost_cols<T, V>(u3, j0, ny);
-    mirror_ghost_cols<T, V>(u2, j0, ny);
   }
 #pragma unroll
   for (int q = 0; q < V; ++q) F3c[q] = mx2[q] = mx3[q] = my2[q] = k3[q] = us3[q] = vs3[q] = rho3[q] = (T)0;
   bool flat2 = row_flat<T, V>(F2), flat1 = row_flat<T, V>(F1), flat0;  // rows r-2, r-1, r all-equal tests
   Row<T, V> Fn, un, vn;  // prefetched: F row r, u / v row r-1
   load_F(Fn, r0);
-  load_u(un, r0 - 1);
-  load_v(vn, r0 - 1);
+  zero_row(un); zero_row(vn);   // (row ra-2: unused, see above)
   for (int r = r0; r <= r1; ++r) {
     Row<T, V> F0 = Fn, u1 = un;
     const Row<T, V> v1 = vn;
@@ -1961,7 +1963,12 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
   T Fnx[V], usnx[V], vsnx[V], pnx[V];  // row r, prefetched one iteration ahead
   load_c<T, V>(Fnx, rowptr(F, ra - 2));
   load_s<T, V>(usnx, rowptr(us, ra - 2));
-  load_s<T, V>(vsnx, rowptr(vs, ra - 2));
+  if (YFIRST) {
+    load_s<T, V>(vsnx, rowptr(vs, ra - 2));
+  } else {
+#pragma unroll
+    for (int q = 0; q < V; ++q) vsnx[q] = (T)0;
+  }
   load_c<T, V>(pnx, rowptr(p, ra - 2));
   unsigned int viol = 0;
   for (int r = ra - 2; r <= rb + 3; ++r) {
@@ -1973,7 +1980,9 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
     if (r < rb + 3) {
       load_c<T, V>(Fnx, rowptr(F, r + 1));
       load_s<T, V>(usnx, rowptr(us, r + 1));
-      load_s<T, V>(vsnx, rowptr(vs, r + 1));
+      // x first: the y sweep trails the pipeline and only touches the chunk's own rows, so v* of the
+      // lead-in / lead-out rows is never used (the stored v of a row is written by the chunk that owns it)
+      if (YFIRST || (r + 1 >= ra && r + 1 <= rb)) load_s<T, V>(vsnx, rowptr(vs, r + 1));
       load_c<T, V>(pnx, rowptr(p, r + 1));
     }
     {  // update_uv for row r (:269-280): ur / vr hold u*[r] / v*[r]

@@ -18,7 +18,7 @@ for kv in [x for x in a.set.split(",") if x]:
 e.set_init_F(a.ic)
 done = 0
 for tgt in [int(x) for x in a.at.split(",")]:
-    e.step(tgt - done); e.sync(); done = tgt
+    e.step(max(0, tgt - done)); e.sync(); done = max(done, tgt)
     t0 = time.perf_counter(); e.step(10); e.sync(); w = 1e5 * (time.perf_counter() - t0); done += 10
     prof = e.profile_steps(4); done += 4
     print("step %5d: wall %7.1f us/step | " % (tgt, w) + "  ".join("%s %.0f" % (k[2:], us) for k, (us, n) in sorted(prof.items())), flush=True)
