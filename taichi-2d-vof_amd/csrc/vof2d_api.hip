@@ -1490,6 +1490,13 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
     *value = (int64_t)v;
     return VOF_OK;
   }
+  if (!strcmp(name, "tb_plan_active")) {   // 1 if the last fused step's k_jacobi_tb launches ran the equal-cost work plan (tb_make_plan)
+    unsigned long long v = 0;
+    HIPCHK(h, hipMemcpyAsync(&v, h->d_tbmask + 2 * TB_BANDS, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *value = (int64_t)v;
+    return VOF_OK;
+  }
   if (!strcmp(name, "exchange_graph_steps")) {  // steps vof_step_exchange replayed from a captured graph
     *value = h->xchg_graph_steps;
     return VOF_OK;

@@ -693,3 +693,40 @@ def test_baseline_config4_2048_bubble_fp32_full_size(hip_api):
     # ghost cells satisfy set_BC (2dvof.py:162-189) at full size in fp32 too
     F = a.get("F")
     assert np.array_equal(F[:, 0], F[:, 1]) and np.array_equal(F[0, :], F[1, :]) and np.array_equal(F[-1, :], F[-2, :])
+
+
+@pytest.mark.parametrize("nx,ny,dtype", [(420, 300, "f64"), (130, 520, "f64"), (200, 260, "f32"), (64, 130, "f64")])   # (the CPU oracle is slow on subnormals)
+def test_equal_cost_work_plan_of_the_fused_jacobi(hip_api, oracle_api, nx, ny, dtype):
+    """k_jacobi_tb's work plan (tb_make_plan): when the launches of a step meet the tiny-numerator
+    tier of the exact division, the next step cuts the tile columns into chunks of equal cost instead
+    of equal length.  Which rows a wave takes must never change a value: a pressure field with a
+    band of tiny values (what the decaying front of the iteration looks like) through eight fused
+    steps, plan active, equals the oracle value for value -- and equals the same run with the
+    plan switched off."""
+    tiny = 1e-290 if dtype == "f64" else 1e-32
+    rng = np.random.default_rng(nx + ny)
+    p0 = np.zeros((nx + 2, ny + 2))
+    i, j = np.meshgrid(np.arange(nx + 2), np.arange(ny + 2), indexing="ij")
+    r = np.hypot(i - 0.4 * nx, j - 0.3 * ny)
+    ring = (r > 0.25 * min(nx, ny)) & (r < 0.45 * min(nx, ny))
+    p0[ring] = tiny * rng.uniform(0.5, 2.0, size=int(ring.sum()))
+    p0[r <= 0.25 * min(nx, ny)] = 1.0            # ordinary values inside the ring, exact zeros outside
+    engines = []
+    for api, adapt in ((hip_api, 1), (hip_api, 0), (oracle_api, None)):
+        e = engine(api, nx, ny, dtype, "f32", ic=1, gy=0.0)   # no forcing: the ring stays a ring of tiny values for a few steps
+        if adapt is not None:
+            e.set_param("jacobi_tb_adapt", adapt)
+        e.set("p", p0)
+        engines.append(e)
+    a, a0, b = engines
+    active = []
+    for step in range(1, 9):
+        for e in engines:
+            e.step(1)
+        assert_fields_same(a, b, ctx="plan on, step %d" % step)
+        assert_fields_same(a0, b, ctx="plan off, step %d" % step)
+        active.append(a.get_counter("tb_plan_active"))
+        assert a0.get_counter("tb_plan_active") == 0
+    # the first step has nothing to go by; from the second on the plan is in use (the grid is wide
+    # enough for more than one tile column only in the larger cases -- a single column is planned too)
+    assert active[0] == 0 and any(active[1:]), active
