@@ -12,6 +12,7 @@ Two carriers with the same four methods (`broadcast_bytes`, `allreduce_max`, `ba
   rendezvous directory on the node, and reductions run on the library's own RCCL communicator
   (vof_comm_allreduce_max).  One node only -- which is what row strips over xGMI are for.
 """
+import base64
 import io
 import json
 import os
@@ -21,14 +22,26 @@ import time
 import numpy as np
 
 
+def _npy_bytes(a):
+    buf = io.BytesIO()
+    np.save(buf, np.asarray(a), allow_pickle=False)
+    return buf.getvalue()
+
+
 def _dumps(obj):
     """Rendezvous payloads are data, never code: JSON for plain values, the .npy format (no pickled
-    objects) for arrays.  Nothing read from the rendezvous directory is ever unpickled."""
+    objects) for arrays -- bare, or base64-wrapped inside a JSON structure.  Nothing read from the
+    rendezvous directory is ever unpickled."""
     if isinstance(obj, np.ndarray):
-        buf = io.BytesIO()
-        np.save(buf, obj, allow_pickle=False)
-        return b"NPY0" + buf.getvalue()
-    return b"JSN0" + json.dumps(obj).encode()
+        return b"NPY0" + _npy_bytes(obj)
+
+    def enc(o):
+        if isinstance(o, np.ndarray):
+            return {"__npy__": base64.b64encode(_npy_bytes(o)).decode("ascii")}
+        if isinstance(o, np.generic):
+            return o.item()
+        raise TypeError("rendezvous payloads are JSON values and arrays, not %r" % type(o).__name__)
+    return b"JSN0" + json.dumps(obj, default=enc).encode()
 
 
 def _loads(data):
@@ -36,7 +49,11 @@ def _loads(data):
     if tag == b"NPY0":
         return np.load(io.BytesIO(body), allow_pickle=False)
     if tag == b"JSN0":
-        return json.loads(body.decode())
+        def dec(d):
+            if set(d) == {"__npy__"}:
+                return np.load(io.BytesIO(base64.b64decode(d["__npy__"])), allow_pickle=False)
+            return d
+        return json.loads(body.decode(), object_hook=dec)
     raise ValueError("rendezvous: unknown payload tag %r" % (tag,))
 
 

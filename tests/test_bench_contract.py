@@ -112,3 +112,39 @@ def test_rendezvous_directory_must_be_private(tmp_path):
     ok2 = EnvComm(1, 2, 1, rdzv_dir=ok.dir)
     with pytest.raises(ValueError):
         ok2.broadcast_object(None)
+
+
+def _run_bench(args, env=None, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=dict(_clean_env(), **(env or {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_strip_path_with_one_rank_native_carrier_and_cost_probe():
+    """The N > 1 code path of bench.py driven with one rank (--force-dist): supervisor -> child, EnvComm
+    rendezvous, StripSolver, the cost probe + re-cut block (VOF2D_BENCH_TEST_BALANCE), timed region,
+    single-GPU reference leg skipped for a non-default grid."""
+    d, err = _run_bench(["--force-dist", "--nx", "1024", "--steps", "6", "--warmup", "2", "--jacobi-sweeps-timed", "20"],
+                        env={"VOF2D_BENCH_TEST_BALANCE": "1"})
+    assert d["n_gpus"] == 1 and d["config"]["rows_per_rank"] == [1024] and d["value"] > 0
+    assert d["config"]["exchange"] == "none" and "cost probe failed" not in err
+
+
+@pytest.mark.gpu
+def test_bench_strip_path_with_one_rank_torch_carrier():
+    d, err = _run_bench(["--force-dist", "--exchange", "torch", "--nx", "1024", "--steps", "6", "--warmup", "2",
+                         "--jacobi-sweeps-timed", "20"])
+    assert d["n_gpus"] == 1 and d["config"]["rows_per_rank"] == [1024] and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_watchdog_falls_back_to_the_second_carrier():
+    """A native attempt that hangs (VOF2D_BENCH_TEST_HANG) is killed by the supervisor after
+    --attempt-timeout and the torch.distributed carrier produces the line."""
+    d, err = _run_bench(["--force-dist", "--nx", "512", "--steps", "4", "--warmup", "2", "--jacobi-sweeps-timed", "20",
+                         "--attempt-timeout", "8"], env={"VOF2D_BENCH_TEST_HANG": "native"})
+    assert "native attempt exceeded" in err and d["value"] > 0
