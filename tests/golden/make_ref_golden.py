@@ -3,7 +3,8 @@
 BUILD CONTAINER ONLY (needs /root/reference; listed in .gpurunignore, only the
 ``ref_*.npz`` files it writes travel to the GPU box).
 
-    python tests/golden/make_ref_golden.py --ic 1 --steps 12 [-s]
+    python tests/golden/make_ref_golden.py --ic 1 --steps 1000 --full 2 100 1000 -s      (as shipped: 200 x 200)
+    python tests/golden/make_ref_golden.py --ic 2 --steps 300 --grid 48 80               (rectangular cells)
 
 What it does: runs ``/root/reference/2dvof.py`` unmodified (``runpy.run_path``,
 ``sys.argv = ['2dvof.py', '-ic', N]``) with a pure-Python stand-in for the one
@@ -262,7 +263,7 @@ def digest_steps(steps):
     return sorted(set(range(0, min(steps, 10) + 1)) | set(range(0, steps + 1, 10)) | {steps})
 
 
-def run_reference(ic, steps, save_fig, full):
+def run_reference(ic, steps, save_fig, full, grid=None):
     sys.modules["taichi"] = make_taichi()
     sys.path.insert(0, REF)
     os.environ.setdefault("MPLBACKEND", "Agg")
@@ -292,7 +293,23 @@ def run_reference(ic, steps, save_fig, full):
     os.chdir(work)
     sys.argv = ["2dvof.py", "-ic", str(ic)] + (["-s"] if save_fig else [])
     try:
-        g = runpy.run_path(os.path.join(REF, "2dvof.py"), run_name="__main__")
+        path = os.path.join(REF, "2dvof.py")
+        if grid is None:
+            g = runpy.run_path(path, run_name="__main__")
+        else:
+            # the reference's grid size is an edit-the-source constant (:19-20): the same text with ONLY
+            # the two literals of `nx = 200` / `ny = 200` replaced (line numbers unchanged, so the
+            # kernels' source is still read from the reference file itself)
+            tree = ast.parse(open(path).read(), filename=path)
+            hit = 0
+            for node in tree.body:
+                if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name) \
+                        and node.targets[0].id in ("nx", "ny") and isinstance(node.value, ast.Constant):
+                    node.value = ast.copy_location(ast.Constant(grid[0] if node.targets[0].id == "nx" else grid[1]), node.value)
+                    hit += 1
+            assert hit == 2
+            g = {"__name__": "__main__", "__file__": path}
+            exec(compile(tree, path, "exec"), g)
     finally:
         sys.argv = argv
         os.chdir(cwd)
@@ -312,9 +329,11 @@ def main():
                     help="steps whose F,u,v,p are stored in full (default 2 and the last)")
     ap.add_argument("-s", action="store_true", help="pass -s to the reference (PNG path, needs >= 100 steps)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--grid", type=int, nargs=2, default=None, metavar=("NX", "NY"),
+                    help="run the reference text with its two grid-size literals (:19-20) replaced (default: as shipped, 200 200)")
     a = ap.parse_args()
     full = sorted(set(a.full if a.full is not None else (2, a.steps)) | {0})
-    nx, ny, kept, rows, const, pngs, shown = run_reference(a.ic, a.steps, a.s, full)
+    nx, ny, kept, rows, const, pngs, shown = run_reference(a.ic, a.steps, a.s, full, a.grid)
     out = {"meta": np.array([nx, ny, a.ic, 0, 1]),      # same meta as make_golden.py: f64, coord cast kept
            "steps": np.array([s for s in full if s > 0]), "nsteps": np.array(a.steps), "F_0": kept[0]["F"],
            "const_names": np.array(sorted(const)), "const": np.array([const[k] for k in sorted(const)]),
@@ -328,7 +347,8 @@ def main():
     out["digest_sha256"] = np.array([r[1] for r in rows])
     out["digest_sum"] = np.array([r[2] for r in rows])
     out["digest_absmax"] = np.array([r[3] for r in rows])
-    path = a.out or os.path.join(HERE, "ref_ic%d_200_f64.npz" % a.ic)
+    path = a.out or os.path.join(HERE, ("ref_ic%d_200_f64.npz" % a.ic) if a.grid is None else
+                                 ("ref_ic%d_%dx%d_f64.npz" % (a.ic, nx, ny)))
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

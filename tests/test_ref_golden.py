@@ -1,6 +1,7 @@
 """Vectors produced by executing the reference's own source text (tests/golden/ref_*.npz,
 made by tests/golden/make_ref_golden.py in the build container: /root/reference/2dvof.py run
-unmodified under a pure-Python stand-in for the taichi module, 200 x 200 as shipped, doubles).
+unmodified under a pure-Python stand-in for the taichi module, 200 x 200 as shipped, doubles; plus
+three runs of the same text with only its grid-size literals replaced, for rectangular cells).
 
 These pin the oracle -- and through it, or directly, the HIP kernels -- to the reference's text
 rather than to a reading of it: every field the reference holds (19 arrays) after steps 0..10, every
@@ -64,14 +65,24 @@ def replay(api, name, fields, who, max_step=None):
     return e, ref
 
 
+SHIPPED = ("ref_ic1_200_f64", "ref_ic2_200_f64", "ref_ic3_200_f64")
+# the reference text with only its two grid-size literals (:19-20) replaced: rectangular cells
+# (dx != dy -- the general Jacobi stencil and the `qp = (fmax - Ftd) * dx` of the y sweep, :417), odd sizes
+RESIZED = ("ref_ic1_96x40_f64", "ref_ic2_48x80_f64", "ref_ic3_33x17_f64")
+
+
 def test_reference_vectors_present():
-    assert {"ref_ic1_200_f64", "ref_ic2_200_f64", "ref_ic3_200_f64"} <= set(REF_CASES)
-    for name in REF_CASES:
+    assert set(SHIPPED) | set(RESIZED) <= set(REF_CASES)
+    for name in SHIPPED:
         ref = Ref(name)
-        assert (ref.nx, ref.ny) == (200, 200) and ref.nsteps >= 3      # the shipped size; odd and even istep
+        assert (ref.nx, ref.ny) == (200, 200) and ref.nsteps == 1000      # the shipped size; odd and even istep
         # constants the reference derived at Python scope (2dvof.py:47-50)
         c = dict(zip((str(k) for k in ref.z["const_names"]), ref.z["const"]))
         assert c["dx"] == 0.00050000002374872565 and c["dt"] == 4e-6 and c["sigma"] == 0.007
+    for name in RESIZED:
+        ref = Ref(name)
+        c = dict(zip((str(k) for k in ref.z["const_names"]), ref.z["const"]))
+        assert ref.nx != ref.ny and c["dx"] != c["dy"] and ref.nsteps >= 300
 
 
 @pytest.mark.parametrize("name", REF_CASES)
@@ -97,6 +108,8 @@ def test_numpy_oracle_reproduces_reference_run(name):
 def test_reference_png_and_gui_path(name):
     """-s of the reference itself (:563-571): one PNG per 100 steps, numbered from 000000."""
     ref = Ref(name)
+    if name not in SHIPPED:
+        pytest.skip("-s was passed to the shipped-size runs only")
     pngs = [str(p) for p in ref.z["pngs"]]
     assert pngs == ["%06d-f.png" % k for k in range(ref.nsteps // 100)]
     assert int(ref.z["gui_shown"]) == ref.nsteps // 100
