@@ -593,6 +593,8 @@ def main():
                         solver.close()
                     if new_parts is not None:
                         parts = [tuple(pr) for pr in new_parts]
+                    # (a new strip handle and with it a new RCCL communicator: ncclCommInitRank on one node takes
+                    # about a second, at most twice per run, well inside the supervisor's limit)
                     solver = make_solver(parts)       # from the initial condition again
                     if new_parts is None:
                         break
