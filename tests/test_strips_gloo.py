@@ -88,6 +88,9 @@ def test_strips_equal_single_domain(oracle_api, tmp_path, nx, ny, ic, dtype, wor
     it, res = ref.solve_p_residual(1e-9, 40, 10)
     assert int(z["it"]) == it and float(z["res"]) == res
     assert same(z["p_after"][1:-1], ref.get("p")[1:-1])
+    it2, res2 = ref.solve_p(1e-3, 100, 25, "rel")      # vof_solve_p, relative criterion
+    assert int(z["it2"]) == it2 and float(z["res2"]) == res2 and it2 % 25 == 0
+    assert same(z["p_after2"][1:-1], ref.get("p")[1:-1])
 
 
 def _envcomm_worker(rank, world, rdzv, out):
