@@ -406,7 +406,7 @@ struct L {
     return h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
   }
   // the work plan of the step's five-sweep launches (see tb_make_plan): active on parity-keyed step
-  // sequences (adapt_par = istep & 1), square or not, two columns per lane, up to 64 tile columns
+  // sequences (adapt_par = istep & 1), square or not, two columns per lane, up to TB_COLS tile columns
   static int tb_cols(const vof2d_ctx* h) { return (sizeof(T) == 4 && h->tb_wide) ? 4 : V; }   // columns per lane of the fused Jacobi
   static TbPlan tb_plan(vof2d_ctx* h, int adapt_par) {
     TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
@@ -418,9 +418,9 @@ struct L {
     if constexpr (sizeof(T) == 4) R = tb_cols(h) == 4 ? jacobi_tb_plan<5, 4>(h, sq, ntt) : jacobi_tb_plan<5, V>(h, sq, ntt);
     else R = jacobi_tb_plan<5, V>(h, sq, ntt);
     const long waves = (long)blocks_for(h, ntt, R) * 4;
-    if (ntt > 64 || waves > kTbPlanWaves || (R < 32 && ntt >= 48 && h->tb_narrow != 0)) return tp;
+    if (ntt > TB_COLS || waves > kTbPlanWaves || (R < 32 && ntt >= 48 && h->tb_narrow != 0)) return tp;
     tp.masks = h->d_tbmask;
-    tp.plan = h->d_tbmask + 2 * TB_BANDS;
+    tp.plan = h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64);
     tp.ntt = ntt; tp.R = R; tp.waves = (int)waves; tp.par = adapt_par;
     return tp;
   }
@@ -1000,8 +1000,8 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
     h->f_home = h->fld[fF];
     if (hipMalloc(reinterpret_cast<void**>(&h->d_courant), 4 * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
     if (hipMemsetAsync(h->d_courant, 0, 4 * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
-    if (hipMalloc(reinterpret_cast<void**>(&h->d_tbmask), (2 * TB_BANDS + 1 + kTbPlanWaves) * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
-    if (hipMemsetAsync(h->d_tbmask, 0, (2 * TB_BANDS + 1 + kTbPlanWaves) * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_tbmask), (2 * TB_BANDS * (TB_COLS / 64) + 1 + kTbPlanWaves) * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
+    if (hipMemsetAsync(h->d_tbmask, 0, (2 * TB_BANDS * (TB_COLS / 64) + 1 + kTbPlanWaves) * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
   } while (0);
@@ -1492,7 +1492,7 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
   }
   if (!strcmp(name, "tb_plan_active")) {   // 1 if the last fused step's k_jacobi_tb launches ran the equal-cost work plan (tb_make_plan)
     unsigned long long v = 0;
-    HIPCHK(h, hipMemcpyAsync(&v, h->d_tbmask + 2 * TB_BANDS, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&v, h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64), sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *value = (int64_t)v;
     return VOF_OK;

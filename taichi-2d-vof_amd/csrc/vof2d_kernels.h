@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void k_predictor(Geom g, Consts<T> c, const T*
 // waves, short chunks inside the band, slightly longer ones elsewhere, so that all waves end
 // together again.  Which rows a wave takes never changes a value (every cell is computed from the
 // same operands whatever the chunking; the parity tests run with the plan active).
-//   TbPlan::masks  two sets of TB_BANDS words, bit j = tile column j: a step reads set (istep & 1)
+//   TbPlan::masks  two sets of TB_BANDS x (TB_COLS / 64) words, one bit per tile column: a step reads set (istep & 1)
 //                  -- what the previous step's launches reported -- and reports into the other, which
 //                  this step's planner clears first (its last readers were the previous step's launches)
 //   TbPlan::plan   [0] = 1 if a plan is active (else the uniform layout), [1 + wave] = the wave's
@@ -662,11 +662,12 @@ __global__ __launch_bounds__(256) void k_predictor(Geom g, Consts<T> c, const T*
 // The planner is one extra wave of k_momentum's launch (the kernel in front of the Jacobi launches
 // in the fused step): it runs beside the other waves, off the critical path.
 constexpr int TB_BANDS = 64;          // row bands of the hit masks
+constexpr int TB_COLS = 128;          // tile columns the masks cover (two 64-bit words per band): grids up to ~14 800 wide
 constexpr int TB_SLOW10 = 20;         // cost of a band row in tenths of an ordinary row
 struct TbPlan {
   unsigned long long* masks;          // nullptr: no plan (uniform layout)
   unsigned long long* plan;
-  int ntt, R, waves, par;             // tile columns (<= 64), uniform chunk length, waves of a launch, istep & 1
+  int ntt, R, waves, par;             // tile columns (<= TB_COLS), uniform chunk length, waves of a launch, istep & 1
 };
 __device__ __forceinline__ unsigned long long plan_pack(int tj, int ra, int rb) {
   return (unsigned long long)(unsigned)tj | ((unsigned long long)(unsigned)ra << 8) | ((unsigned long long)(unsigned)rb << 36);
@@ -675,14 +676,17 @@ __device__ __forceinline__ int tb_band_of(const Geom& g, int i) {   // row -> ba
   const int rows = g.ihi - g.ilo + 1, h = (rows + TB_BANDS - 1) / TB_BANDS;
   return (i - g.ilo) / h;
 }
+// word index of (mask set, band, tile column) and the column's bit in it
+__device__ __forceinline__ int tb_word(int set, int b, int tj) { return (set * TB_BANDS + b) * (TB_COLS / 64) + (tj >> 6); }
 // One block of 256 threads (the planner block of k_momentum's launch; it must not outlast the
 // launch's other waves, so the per-chunk work is spread over all its threads).  32-bit integers.
 struct TbPlanShared {
-  unsigned prefix[64][TB_BANDS + 1];   // prefix[j][b] = cost of rows [0, b * bh) of tile column j, in tenths of a row
-  unsigned long long band[TB_BANDS];   // the reported (band, column) bits
-  int first[65];                       // first wave of column j; first[ntt] = planned waves
-  int n[64];                           // chunks of column j
+  unsigned prefix[TB_COLS][TB_BANDS + 1];      // prefix[j][b] = cost of rows [0, b * bh) of tile column j, in tenths of a row
+  unsigned long long band[TB_BANDS][TB_COLS / 64];   // the reported (band, column) bits
+  int first[TB_COLS + 1];                      // first wave of column j; first[TB_COLS] = planned waves
+  int n[TB_COLS];                              // chunks of column j
 };
+__device__ __forceinline__ bool tb_bit(const TbPlanShared& sh, int b, int j) { return ((sh.band[b][j >> 6] >> (j & 63)) & 1ull) != 0ull; }
 // row position (0 .. rows) where the cumulative cost of column j reaches T
 __device__ __forceinline__ int tb_pos(const TbPlanShared& sh, int j, unsigned T, int rows, int bh) {
   int lo = 0, hi = TB_BANDS;           // largest b with prefix[j][b] <= T
@@ -690,69 +694,111 @@ __device__ __forceinline__ int tb_pos(const TbPlanShared& sh, int j, unsigned T,
     const int mid = (lo + hi) >> 1;
     if (sh.prefix[j][mid] <= T) lo = mid; else hi = mid;
   }
-  const bool slow = ((sh.band[lo] >> j) & 1ull) != 0ull;
+  const bool slow = tb_bit(sh, lo, j);
   const unsigned rest = T - sh.prefix[j][lo];
   int pos = lo * bh + (int)(slow ? rest / (unsigned)TB_SLOW10 : rest / 10u);
   const int bend = (lo + 1) * bh;
   if (pos > bend) pos = bend;
   return pos < rows ? pos : rows;
 }
+__device__ __forceinline__ int tb_wave_sum(int v) {
+  for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft, 64);
+  return v;
+}
 __device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) {
+  constexpr int CW = TB_COLS / 64;
   const int t = threadIdx.x, lane = t & 63;
-  const unsigned long long* rd = tp.masks + (size_t)tp.par * TB_BANDS;
-  unsigned long long* wr = tp.masks + (size_t)(tp.par ^ 1) * TB_BANDS;
   const int rows = g.ihi - g.ilo + 1, bh = (rows + TB_BANDS - 1) / TB_BANDS;
-  const unsigned long long mine = rd[lane];     // band `lane` (nobody writes the read set during this step)
-  const bool any = __any(mine != 0ull);         // (the same in all four waves)
+  unsigned long long mine[CW];                  // band `lane` (nobody writes the read set during this step)
+  bool some = false;
+#pragma unroll
+  for (int w = 0; w < CW; ++w) {
+    mine[w] = tp.masks[tb_word(tp.par, lane, 0) + w];
+    some = some || mine[w] != 0ull;
+  }
+  const bool any = __any(some);                 // (the same in all four waves)
   if (t < 64) {
-    wr[lane] = 0ull;                            // this step's launches report into the other set
-    sh.band[lane] = mine;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) {
+      tp.masks[tb_word(tp.par ^ 1, lane, 0) + w] = 0ull;   // this step's launches report into the other set
+      sh.band[lane][w] = mine[w];
+    }
     if (lane == 0) tp.plan[0] = any ? 1ull : 0ull;
   }
   if (!any) return;                             // block-uniform
   __syncthreads();
-  if (t < 64) {   // wave 0: per column, the cost prefix over the bands and the number of chunks
-    const int j = lane;
-    unsigned cost = 0;
-    for (int b = 0; b < TB_BANDS; ++b) {
-      sh.prefix[j][b] = cost;
-      const int r0 = b * bh, r1 = r0 + bh < rows ? r0 + bh : rows;
-      if (r1 > r0) cost += (unsigned)(r1 - r0) * (((sh.band[b] >> j) & 1ull) ? (unsigned)TB_SLOW10 : 10u);
+  if (t < 64) {   // wave 0: per column (lane j and j + 64), the cost prefix over the bands and the number of chunks
+    unsigned cost[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int j = lane + 64 * c;
+      unsigned acc = 0;
+      for (int b = 0; b < TB_BANDS; ++b) {
+        sh.prefix[j][b] = acc;
+        const int r0 = b * bh, r1 = r0 + bh < rows ? r0 + bh : rows;
+        if (r1 > r0) acc += (unsigned)(r1 - r0) * (tb_bit(sh, b, j) ? (unsigned)TB_SLOW10 : 10u);
+      }
+      sh.prefix[j][TB_BANDS] = acc;
+      cost[c] = j < tp.ntt ? acc : 0u;
     }
-    sh.prefix[j][TB_BANDS] = cost;
-    if (j >= tp.ntt) cost = 0;
-    unsigned total = cost;
-    for (int sft = 32; sft > 0; sft >>= 1) total += __shfl_xor(total, sft, 64);
+    unsigned total = 0;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) total += (unsigned)tb_wave_sum((int)cost[c]);
     // chunks per column, proportional to its cost (at least one), within the waves of a launch
     const int nmax = rows >= 4 ? rows / 4 : 1;
-    int n = j < tp.ntt ? (int)(((unsigned long long)cost * (unsigned)tp.waves) / total) : 0;
-    if (j < tp.ntt && n < 1) n = 1;
-    if (n > nmax) n = nmax;
-    int sum = n;
-    for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
-    // (the floor leaves a few waves over: one more for the first columns; never more than `waves`)
-    if (sum < tp.waves && j < tp.ntt && j < tp.waves - sum && n < nmax) n += 1;
-    for (int guard = 0; guard < 4096; ++guard) {   // the at-least-one rule can overshoot on tiny grids: trim the largest
-      sum = n;
-      for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
-      if (sum <= tp.waves) break;
-      int mx = n;
-      for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(mx, sft, 64); mx = o > mx ? o : mx; }
-      const unsigned long long who = __ballot(n == mx);
-      if (lane == __ffsll((long long)who) - 1) n -= 1;
+    int n[CW], sum = 0;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int j = lane + 64 * c;
+      n[c] = j < tp.ntt ? (int)(((unsigned long long)cost[c] * (unsigned)tp.waves) / total) : 0;
+      if (j < tp.ntt && n[c] < 1) n[c] = 1;
+      if (n[c] > nmax) n[c] = nmax;
+      sum += tb_wave_sum(n[c]);
     }
-    int first = n;   // inclusive prefix sum -> the column's first wave
-    for (int sft = 1; sft < 64; sft <<= 1) { const int o = __shfl_up(first, sft, 64); if (lane >= sft) first += o; }
-    sh.n[j] = n;
-    sh.first[j] = first - n;
-    if (lane == 63) sh.first[64] = first;
+    // (the floor leaves a few waves over: one more for the first columns; never more than `waves`)
+    const int left = tp.waves - sum;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int j = lane + 64 * c;
+      if (left > 0 && j < tp.ntt && j < left && n[c] < nmax) n[c] += 1;
+    }
+    for (int guard = 0; guard < 8192; ++guard) {   // the at-least-one rule can overshoot on tiny grids: trim the largest
+      sum = 0;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) sum += tb_wave_sum(n[c]);
+      if (sum <= tp.waves) break;
+      int mx = 0;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) mx = n[c] > mx ? n[c] : mx;
+      for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(mx, sft, 64); mx = o > mx ? o : mx; }
+      bool done = false;                         // the first column holding the maximum gives one up
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        const unsigned long long who = __ballot(!done && n[c] == mx);
+        if (who != 0ull) {
+          if (!done && lane == __ffsll((long long)who) - 1) n[c] -= 1;
+          done = true;
+        }
+      }
+    }
+    int base = 0;   // prefix sums over the 64-column halves -> every column's first wave
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int j = lane + 64 * c;
+      int incl = n[c];
+      for (int sft = 1; sft < 64; sft <<= 1) { const int o = __shfl_up(incl, sft, 64); if (lane >= sft) incl += o; }
+      sh.n[j] = n[c];
+      sh.first[j] = base + incl - n[c];
+      base += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) sh.first[TB_COLS] = base;
   }
   __syncthreads();
-  const int planned = sh.first[64];
-  for (int w = t; w < tp.waves; w += 256) {
+  const int planned = sh.first[TB_COLS];
+  for (int w = t; w < tp.waves; w += (int)blockDim.x) {
     unsigned long long e = plan_pack(0, 1, 0);   // waves past the planned ones: empty
     if (w < planned) {
-      int lo = 0, hi = 64;                       // the column of wave w: largest j with first[j] <= w
+      int lo = 0, hi = TB_COLS;                  // the column of wave w: largest j with first[j] <= w
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (sh.first[mid] <= w) lo = mid; else hi = mid;
@@ -1408,8 +1454,7 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
   }
   if constexpr (RESID) norm_publish<T>(upd, pmx, norm_bits);
   if (tp.masks != nullptr && __any(hit != 0) && lane == 0) {   // report the (row band, tile column) cells of this chunk
-    unsigned long long* wr = tp.masks + (size_t)(tp.par ^ 1) * TB_BANDS;
-    for (int b = tb_band_of(g, ra); b <= tb_band_of(g, rb); ++b) atomicOr(wr + b, 1ull << tj);
+    for (int b = tb_band_of(g, ra); b <= tb_band_of(g, rb); ++b) atomicOr(tp.masks + tb_word(tp.par ^ 1, b, tj), 1ull << (tj & 63));
   }
 }
 
