@@ -7,10 +7,17 @@
  * with the prefix `ovof_` so the parity tests can drive oracle and HIP
  * library through one code path.
  *
- * PARITY UNPINNED: taichi==1.4.1 cannot be installed in this image and the
- * reference's test/ scripts hold no golden vectors; this restatement is
- * pinned only against the independent NumPy restatement
- * (oracle/vof_oracle_np.py) and the self-generated fixtures in tests/golden/.
+ * PARITY PIN: taichi==1.4.1 cannot be installed in this image and the
+ * reference's test/ scripts hold no golden vectors.  This restatement is
+ * pinned to the reference's own source text, executed: tests/golden/ref_*.npz
+ * come from /root/reference/2dvof.py run unmodified under a pure-Python
+ * stand-in for the taichi module (tests/golden/make_ref_golden.py: 200 x 200
+ * as shipped, doubles, -ic 1/2/3, 1000 steps; three rectangular-cell runs with
+ * only the grid-size literals replaced), and tests/test_ref_golden.py requires
+ * all 19 arrays of every recorded step to be reproduced exactly.  NOT pinned:
+ * Taichi's code generation (fast_math contraction / reassociation).  Also
+ * checked against the independent NumPy restatement (oracle/vof_oracle_np.py)
+ * and the self-generated fixtures in tests/golden/.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  Build: see oracle/Makefile (-O2 -ffp-contract=off).

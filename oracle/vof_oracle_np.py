@@ -5,13 +5,21 @@ NumPy restatement of the hot path of the reference solver
 (/root/reference/2dvof.py), vectorised one statement group per Taichi
 top-level ``for`` (every such loop is a barrier).
 
-PARITY UNPINNED: the reference needs ``taichi==1.4.1`` which is not
-installable in this image (no wheel, no network) and its ``test/`` scripts
-hold no golden vectors, so nothing here can be checked against real Taichi
-output.  What pins this file instead: it agrees value-for-value with the
-independent scalar-C restatement in ``oracle/vof_oracle.c`` (see
-``tests/test_oracle.py``) and with the committed self-generated fixtures
-under ``tests/golden/``.
+PARITY PIN: the reference needs ``taichi==1.4.1``, which is not installable in
+this image (no wheel, no network), and its ``test/`` scripts hold no golden
+vectors.  What this file is checked against instead is the reference's OWN
+SOURCE TEXT, executed: ``tests/golden/make_ref_golden.py`` runs
+``/root/reference/2dvof.py`` unmodified in the build container under a
+pure-Python stand-in for the ``taichi`` module (200 x 200 as shipped, doubles,
+-ic 1/2/3, 1000 steps; plus three rectangular-cell runs with only the grid-size
+literals replaced) and commits the results as ``tests/golden/ref_*.npz``;
+``tests/test_ref_golden.py`` requires this module (first 20 steps) and the C
+restatement (every recorded step) to reproduce all 19 arrays of those runs
+exactly.  NOT pinned: Taichi's code generation (``fast_math`` contraction /
+reassociation) -- real Taichi output may differ from the reference's text in
+the last bits.  It also agrees value-for-value with the independent scalar-C
+restatement in ``oracle/vof_oracle.c`` (``tests/test_oracle.py``) and with the
+committed self-generated fixtures under ``tests/golden/``.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may import this module.

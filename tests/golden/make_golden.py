@@ -1,7 +1,8 @@
 """Generates the committed golden fixtures (tests/golden/*.npz).
 
-SELF-GENERATED, NOT TAICHI OUTPUT: taichi==1.4.1 cannot be installed in this
-image, so the fixtures come from the two independent restatements of
+SELF-GENERATED, NOT TAICHI OUTPUT (the vectors made by executing the reference's
+own text are ref_*.npz, see make_ref_golden.py): taichi==1.4.1 cannot be installed in this
+image, so these fixtures come from the two independent restatements of
 /root/reference/2dvof.py in oracle/ (NumPy-vectorised and scalar C); the script
 refuses to write a fixture unless both agree value for value.
 
