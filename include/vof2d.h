@@ -103,9 +103,10 @@ int vof_post_process_f(vof2d_handle h);             /* :452-455 */
 
 /* nsteps iterations of the solver part of the main loop, 2dvof.py:506-528
  * (istep += 1 first; 10 Jacobi sweeps; x/y sweep alternation), using the fused
- * kernel schedule: 5 kernels + one boundary launch per step, replayed from a hipGraph
- * (the first step after set_init_F / set_field / a single verb runs eagerly with the intermediate
- * boundary launch the reference's :518 stands for).  rho/nu/kappa scratch is not materialised. */
+ * kernel schedule: on a full domain four launches per step -- k_momentum, two
+ * five-sweep k_jacobi_tb, k_transport -- replayed from a hipGraph (the first step after set_init_F /
+ * set_field / a single verb runs eagerly with the intermediate boundary launches the reference's
+ * :518 / :525 stand for).  rho/nu/kappa scratch is not materialised. */
 int vof_step(vof2d_handle h, int64_t nsteps);
 /* The same step split at the points where a field becomes final, for drivers that overlap the
  * halo exchange with compute (vof2d/strips.py, vof_step_exchange):
