@@ -1248,8 +1248,11 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
 // max|p_TS| over the owned cells the tile stores, so the residual-terminated solve keeps the TS-sweep
 // fusion.  p_(TS-1) of a row is the previous stage's output one iteration earlier (kept in V extra
 // registers when SQ, where the ring holds products rather than values).
+#ifndef VOF_TB_MINWAVES
+#define VOF_TB_MINWAVES 1
+#endif
 template <typename T, int V, int TS, bool SQ, bool RESID = false>
-__global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
+__global__ __launch_bounds__(256, VOF_TB_MINWAVES) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
                                                     const T* __restrict__ rhs, T* __restrict__ pn, int R,
                                                     int ntt, unsigned long long* __restrict__ norm_bits = nullptr,
                                                     TbPlan tp = TbPlan{nullptr, nullptr, 0, 0, 0, 0}) {
