@@ -659,8 +659,8 @@ __global__ __launch_bounds__(256) void k_predictor(Geom g, Consts<T> c, const T*
 //                  this step's planner clears first (its last readers were the previous step's launches)
 //   TbPlan::plan   [0] = 1 if a plan is active (else the uniform layout), [1 + wave] = the wave's
 //                  tile column and rows, packed (plan_pack)
-// The planner is one extra wave of k_momentum's launch (the kernel in front of the Jacobi launches
-// in the fused step): it runs beside the other waves, off the critical path.
+// The planner is one extra block -- the first -- of k_momentum's launch (the kernel in front of the
+// Jacobi launches in the fused step): it runs beside the other blocks, off the critical path.
 constexpr int TB_BANDS = 64;          // row bands of the hit masks
 constexpr int TB_COLS = 128;          // tile columns the masks cover (two 64-bit words per band): grids up to ~14 800 wide
 constexpr int TB_SLOW10 = 20;         // cost of a band row in tenths of an ordinary row
@@ -893,8 +893,11 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
                                                    const T* __restrict__ u, const T* __restrict__ v,
                                                    T* __restrict__ us, T* __restrict__ vs, T* __restrict__ rhs,
                                                    int R, int ntt, int virt, TbPlan tp) {
-  // the launch's last block is the planner of this step's k_jacobi_tb launches (see tb_make_plan)
-  if (tp.masks != nullptr && blockIdx.x == gridDim.x - 1) {
+  // the launch's FIRST block is the planner of this step's k_jacobi_tb launches (see tb_make_plan): it
+  // starts with the launch and runs beside the other blocks (as the last block it would start when the
+  // last slots free up and add its few microseconds to the kernel's tail)
+  const int plan_blocks = tp.masks != nullptr ? 1 : 0;
+  if (plan_blocks && blockIdx.x == 0) {
     __shared__ TbPlanShared plan_sh;
     tb_make_plan(g, tp, plan_sh);
     return;
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   constexpr int H = ((2 + V - 1) / V) * V;
   WaveTimer wt_(WT_MOMENTUM);
   constexpr int STRIDE = W - 2 * H;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = ((int)blockIdx.x - plan_blocks) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int tj = wave % ntt, ch = wave / ntt;
   const int c0 = 1 - H + tj * STRIDE;
