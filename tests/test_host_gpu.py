@@ -116,3 +116,14 @@ def test_exchange_mode4_equals_phases_plus_copies(own):
     """vof_step_exchange overlap 4 -- the default of bench.py --gpus N -- replayed from the captured
     graph, on an interior strip, next to either wall and on a strip whose bands meet."""
     _loopback_worker("mode4", own[0], own[1])
+
+
+def test_command_line_residual_terminated_solve(tmp_path):
+    """2dvof.py --jacobi-tol / --jacobi-crit (extension): the main loop :513-528 with vof_solve_p in place of
+    the ten fixed sweeps runs headless and reports like the reference."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "2dvof.py"), "-ic", "1", "--dtype", "f64", "--nx", "96", "--ny", "64",
+                        "--jacobi-tol", "1e-3", "--jacobi-crit", "rel", "--jacobi-max", "4000", "--steps", "100"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert ">>> Grid resolution: 96 x 64, dt = 4.00e-06" in r.stdout
+    assert ">>> Number of steps:100  , Time:4.00e-04 sec. Displaying VOF field." in r.stdout
