@@ -211,93 +211,16 @@ class _StdoutToStderr:
         return False
 
 
-def _die_with_parent():
-    # a child must not outlive the process that started it (a launcher that tears its workers down
-    # would otherwise leave GPU-holding orphans): PR_SET_PDEATHSIG = 1
-    import signal
-    ctypes.CDLL(None).prctl(1, int(signal.SIGKILL), 0, 0, 0)
+from vof2d.launch import die_with_parent as _die_with_parent  # noqa: E402
 
 
 # --------------------------------------------------------------------------------------------------
 def launch_workers(a):
-    """`python bench.py --gpus N` with no launcher around it: this process becomes the launcher.  It
-    never touches the GPU (no HIP call, no torch import); it starts N fresh worker processes -- one
-    per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment exactly as
-    torch.distributed.run would set them, plus a private rendezvous directory -- relays rank 0's
-    line and exits with the first non-zero worker code."""
-    import signal
-    import socket
-    import tempfile
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    rdzv = tempfile.mkdtemp(prefix="vof2d_rdzv_")        # mode 0700, unpredictable name
-    argv = [x for x in sys.argv[1:]]
-    procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VOF2D_RDZV_DIR=rdzv,
-                   VOF2D_RDZV_TAG="self_%d" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
-                                      start_new_session=True, preexec_fn=_die_with_parent))
-
-    def kill_all(*_):
-        for p in procs:
-            if p.poll() is None:
-                try:
-                    os.killpg(p.pid, signal.SIGKILL)      # exactly the groups this process started
-                except ProcessLookupError:
-                    pass
-    signal.signal(signal.SIGTERM, lambda s_, f: (kill_all(), sys.exit(128 + s_)))
-    signal.signal(signal.SIGINT, lambda s_, f: (kill_all(), sys.exit(128 + s_)))
-    out0 = b""
-    rc = 0
-    try:
-        # a worker that dies takes the others down (they would wait for it until their watchdogs fire)
-        pending = set(range(a.gpus))
-        import selectors
-        sel = selectors.DefaultSelector()
-        sel.register(procs[0].stdout, selectors.EVENT_READ)
-        eof = False
-        while pending:
-            if not eof:
-                for key, _ in sel.select(timeout=0.2):
-                    chunk = os.read(key.fileobj.fileno(), 65536)
-                    if chunk:
-                        out0 += chunk
-                    else:
-                        eof = True
-                        sel.unregister(key.fileobj)
-            else:
-                time.sleep(0.2)
-            for r in list(pending):
-                code = procs[r].poll()
-                if code is not None:
-                    pending.discard(r)
-                    if code != 0 and rc == 0:
-                        rc = code
-                        print("[bench] worker %d exited with code %d: stopping the others" % (r, code), file=sys.stderr)
-                        kill_all()
-        if not eof:
-            out0 += procs[0].stdout.read() or b""
-    finally:
-        kill_all()
-        try:
-            for n in os.listdir(rdzv):
-                p = os.path.join(rdzv, n)
-                if os.path.isdir(p):
-                    for m in os.listdir(p):
-                        os.remove(os.path.join(p, m))
-                    os.rmdir(p)
-                else:
-                    os.remove(p)
-            os.rmdir(rdzv)
-        except OSError:
-            pass
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    return rc
+    """`python bench.py --gpus N` with no launcher around it: this process becomes the launcher
+    (vof2d/launch.py): it never touches the GPU, starts N fresh workers with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set as torch.distributed.run would, relays rank 0's line."""
+    from vof2d.launch import spawn_ranks
+    return spawn_ranks(__file__, sys.argv[1:], a.gpus)
 
 
 def supervise(a, rank):

@@ -148,9 +148,10 @@ class Engine:
                                            C.byref(it), C.byref(res)), "solve_p_residual")
         return it.value, res.value
 
-    def solve_p(self, tol, max_iters, check_every=100, criterion="rel"):
+    def solve_p(self, tol, max_iters, check_every=10, criterion="abs"):
         """vof_solve_p: sweeps until the residual (\"abs\": max|p_new - p|; \"rel\": that over
-        max(max|p_new|, tiny)) is <= tol; returns (sweeps done, residual)."""
+        max(max|p_new|, tiny)) is <= tol; returns (sweeps done, residual).  Same defaults as
+        StripSolver.solve_p and vof_solve_p_residual (absolute criterion, a check every 10 sweeps)."""
         crit = {"abs": _abi.VOF_RESID_ABS, "rel": _abi.VOF_RESID_REL}[criterion]
         it, res = C.c_int32(), C.c_double()
         self._ck(self.api.solve_p(self._h, float(tol), int(max_iters), int(check_every), crit,

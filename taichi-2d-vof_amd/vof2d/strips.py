@@ -251,7 +251,9 @@ class StripSolver:
         in the invalid fringe, so owned rows are unaffected; no kernel of a later phase writes a
         field whose exchange is in flight (DESIGN.md "strips")."""
         if self.world > 1 and self.exchange_kind == "native":
-            self.eng.step_exchange(nsteps, int(overlap))   # the whole loop in the library
+            # the whole loop in the library; True = the default schedule (mode 4: fused transport, edge bands
+            # first, one send/recv group per step), an int = that mode of vof_step_exchange
+            self.eng.step_exchange(nsteps, 4 if overlap is True else int(overlap))
             return
         with self._ctx():
             for _ in range(nsteps):
@@ -278,6 +280,11 @@ class StripSolver:
         the same rule as vof_solve_p on a single domain: n = min(check_every, max_iters - done)."""
         crit = {"abs": _abi.VOF_RESID_ABS, "rel": _abi.VOF_RESID_REL}[criterion]
         depth = self.halo - 6           # sweeps the deep halo of p covers between two exchanges
+        if self.world > 1 and depth < 1:
+            raise ValueError("solve_p on strips needs jacobi_iters >= 1 (the halo of p covers jacobi_iters sweeps "
+                             "between two exchanges; this solver was made with jacobi_iters = %d)" % depth)
+        if check_every < 1 or max_iters < 0:
+            raise ValueError("check_every must be >= 1 and max_iters >= 0")
         done, res = 0, float("inf")
         first = True
         with self._ctx():

@@ -38,7 +38,12 @@ here because no loop of the hot path reads what another iteration of the same
 loop writes, except the face fluxes ``ax`` / ``ay`` that two iterations store
 with bit-identical expressions.
 
-One deviation from plain CPython, needed to run the text at all:
+Three deviations from plain CPython: (1) reads one row past a field return 0
+(Field.__getitem__; interp_velocity :490-492 does that, undefined behaviour in
+Taichi; --vis only); (2) `x ** 2` on run-time values is x * x as in Taichi, not
+libm's pow(), which is off by an ulp now and then (_Scoper.visit_BinOp;
+find_area :120-124 and get_vnorm_field :486); and (3), needed to run the text
+at all:
 ``cal_nu_rho`` (:200-201) assigns a local ``F`` from the global field ``F``
 (``F = var(0.0, 1.0, F[I])``).  Taichi resolves the right-hand side before the
 local exists; CPython raises UnboundLocalError.  ``_scoped`` renames such
@@ -77,9 +82,18 @@ class Field:
         shape = (shape,) if isinstance(shape, int) else tuple(shape)
         self.a = np.zeros(shape, dtype=np.float64 if dtype is float else dtype)
 
+    oob_reads = 0
+
     def __getitem__(self, idx):
         if idx is None:                       # sigma[None]
             return self.a[()]
+        if isinstance(idx, tuple) and len(idx) == 2 and idx[0] == self.a.shape[0]:
+            # interp_velocity (:490-492) loops i up to imax+1 and reads u[i+1, j] = u[imax+2, j], one row
+            # past the field: undefined in Taichi's release mode (no bounds check).  Reads as 0 here
+            # (what follows a dense field in Taichi's zero-filled root buffer is another field or
+            # padding); only the display vector V[imax+1, :, 0] depends on it.  Counted.
+            Field.oob_reads += 1
+            return self.a.dtype.type(0)
         return self.a[idx]
 
     def __setitem__(self, idx, val):
@@ -162,6 +176,18 @@ class _Scoper(ast.NodeTransformer):
         node.orelse = self._block(node.orelse)
         return node
 
+    def visit_BinOp(self, node):
+        node.left, node.right = self.visit(node.left), self.visit(node.right)
+        # `x ** n`, n an integer literal, on a RUN-TIME value (a field entry, a kernel variable): Taichi
+        # lowers it to repeated multiplication (demote_operations: square-and-multiply), while CPython
+        # hands np.float64 ** 2 to libm's pow(), which is not correctly rounded.  A bare module-level
+        # constant (`dxi ** 2`, :216-261) is folded by Python in Taichi too and stays Python's `**`.
+        if isinstance(node.op, ast.Pow) and isinstance(node.right, ast.Constant) and isinstance(node.right.value, int) \
+                and not (isinstance(node.left, ast.Name) and isinstance(self.glob.get(node.left.id), (int, float))):
+            call = ast.Call(ast.Name("__ti_pow__", ast.Load()), [node.left, node.right], [])
+            return ast.copy_location(call, node)
+        return node
+
     def visit_Assign(self, node):
         node.value = self.visit(node.value)   # right-hand side first, with the names as they were
         for t in node.targets:
@@ -171,6 +197,17 @@ class _Scoper(ast.NodeTransformer):
             else:
                 self.visit(t)
         return node
+
+
+def _ti_pow(a, n):
+    """Taichi's integer power of a run-time value: square-and-multiply, starting from 1."""
+    result, b = type(a)(1), abs(n)
+    while b:
+        if b & 1:
+            result = result * a
+        a = a * a
+        b >>= 1
+    return 1 / result if n < 0 else result
 
 
 def _scoped(fn):
@@ -183,6 +220,7 @@ def _scoped(fn):
     ast.fix_missing_locations(tree)
     ast.increment_lineno(tree, fn.__code__.co_firstlineno - 1)
     ns = {}
+    fn.__globals__["__ti_pow__"] = _ti_pow
     exec(compile(tree, fn.__code__.co_filename, "exec"), fn.__globals__, ns)
     return ns[fn.__name__]
 
@@ -191,6 +229,7 @@ class GUI:
     RELEASE, SPACE = "release", " "
     hook = None                               # called at the top of every iteration of :505
     limit = 0
+    press_space_after_display = False
 
     def __init__(self, *a, **k):
         self._reads = 0
@@ -208,7 +247,14 @@ class GUI:
     def get_events(self, *a):
         if GUI.hook:
             GUI.hook()
+        # --vis: one SPACE release right after every display (:507-509), so the reference's own
+        # event loop walks vis_option through 0..4 and its display branches (:531-559) all run
+        if GUI.press_space_after_display and self._reads > 1 and (self._reads - 1) % 100 == 0:
+            return [types.SimpleNamespace(key=GUI.SPACE)]
         return []
+
+    def arrows(self, orig=None, direction=None, **k):     # flow_visualization.py:55
+        self.arrow_args = (np.array(orig), np.array(direction))
 
     def set_image(self, img):
         self.image = np.asarray(img)
@@ -263,14 +309,25 @@ def digest_steps(steps):
     return sorted(set(range(0, min(steps, 10) + 1)) | set(range(0, steps + 1, 10)) | {steps})
 
 
-def run_reference(ic, steps, save_fig, full, grid=None):
+def run_reference(ic, steps, save_fig, full, grid=None, vis=False):
     sys.modules["taichi"] = make_taichi()
     sys.path.insert(0, REF)
     os.environ.setdefault("MPLBACKEND", "Agg")
     want_digest, want_full = set(digest_steps(steps)), set(full)
-    kept, rows, t0, mod = {}, [], time.time(), {}
+    kept, rows, t0, mod, shown_vis = {}, [], time.time(), {}, {}
 
     def record(g, st):
+        if vis and st > 0 and st % 100 == 0:
+            # what the display branch of :531-559 left behind at this step: vis_option has not been
+            # advanced yet (the injected SPACE is processed after this hook returns)
+            opt = g["vis_option"] % 5
+            d = {"option": opt, "shown": g["gui"].shown}
+            if opt < 4:
+                d["rgb"] = g["rgb_buf"].to_numpy()
+            else:
+                d["V"] = g["V"].to_numpy()
+                d["orig"], d["direction"] = g["gui"].arrow_args
+            shown_vis[st] = d
         if st in want_full:
             kept[st] = {n: g[n].to_numpy() for n in STATE}
         if st in want_digest:
@@ -287,7 +344,7 @@ def run_reference(ic, steps, save_fig, full, grid=None):
             mod["g"] = sys._getframe(2).f_globals
         record(mod["g"], mod["g"]["istep"] - 1)
 
-    GUI.hook, GUI.limit = hook, steps
+    GUI.hook, GUI.limit, GUI.press_space_after_display = hook, steps, vis
     argv, cwd = sys.argv, os.getcwd()
     work = tempfile.mkdtemp(prefix="refrun_")
     os.chdir(work)
@@ -318,7 +375,7 @@ def run_reference(ic, steps, save_fig, full, grid=None):
     const = {k: float(g[k]) for k in ("dx", "dy", "dxi", "dyi", "dt", "Lx", "Ly", "rho_l", "rho_g", "nu_l", "nu_g")}
     const["sigma"] = float(g["sigma"][None])
     pngs = sorted(os.listdir(os.path.join(work, "output")))
-    return g["nx"], g["ny"], kept, rows, const, pngs, g["gui"].shown
+    return g["nx"], g["ny"], kept, rows, const, pngs, g["gui"].shown, shown_vis
 
 
 def main():
@@ -331,9 +388,12 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--grid", type=int, nargs=2, default=None, metavar=("NX", "NY"),
                     help="run the reference text with its two grid-size literals (:19-20) replaced (default: as shipped, 200 200)")
+    ap.add_argument("--vis", action="store_true",
+                    help="inject a SPACE key release after every display so the reference cycles through its five "
+                         "display branches (:531-559); records rgb_buf / V / the gui.arrows arguments at the 100-step marks")
     a = ap.parse_args()
     full = sorted(set(a.full if a.full is not None else (2, a.steps)) | {0})
-    nx, ny, kept, rows, const, pngs, shown = run_reference(a.ic, a.steps, a.s, full, a.grid)
+    nx, ny, kept, rows, const, pngs, shown, shown_vis = run_reference(a.ic, a.steps, a.s, full, a.grid, a.vis)
     out = {"meta": np.array([nx, ny, a.ic, 0, 1]),      # same meta as make_golden.py: f64, coord cast kept
            "steps": np.array([s for s in full if s > 0]), "nsteps": np.array(a.steps), "F_0": kept[0]["F"],
            "const_names": np.array(sorted(const)), "const": np.array([const[k] for k in sorted(const)]),
@@ -342,13 +402,25 @@ def main():
         if st > 0:
             for f in STATE:
                 out["%s_%d" % (f, st)] = kept[st][f]
+    # sha256 of the reference file the vectors came from (tests check it is recorded)
+    out["oob_reads"] = np.array(Field.oob_reads)
+    out["ref_sha256"] = np.array(hashlib.sha256(open(os.path.join(REF, "2dvof.py"), "rb").read()).hexdigest())
+    if shown_vis:
+        out["vis_steps"] = np.array(sorted(shown_vis))
+        for st, d in shown_vis.items():
+            out["vis_option_%d" % st] = np.array(d["option"])
+            for k in ("rgb", "V", "orig", "direction"):
+                if k in d and d[k].size > 40000:      # as-shipped size: digest only (1.3 MB per image)
+                    out["vis_%s_sha256_%d" % (k, st)] = np.array(digest(d[k]))
+                elif k in d:
+                    out["vis_%s_%d" % (k, st)] = d[k]
     # all 19 fields at digest_steps() as sha256 + two moments (diagnostics when a digest differs)
     out["digest_names"] = np.array([r[0] for r in rows])
     out["digest_sha256"] = np.array([r[1] for r in rows])
     out["digest_sum"] = np.array([r[2] for r in rows])
     out["digest_absmax"] = np.array([r[3] for r in rows])
     path = a.out or os.path.join(HERE, ("ref_ic%d_200_f64.npz" % a.ic) if a.grid is None else
-                                 ("ref_ic%d_%dx%d_f64.npz" % (a.ic, nx, ny)))
+                                 ("ref_ic%d_%dx%d_f64%s.npz" % (a.ic, nx, ny, "_vis" if a.vis else "")))
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

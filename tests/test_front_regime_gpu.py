@@ -1,0 +1,121 @@
+"""GPU parity in the regime the sustained headline number runs in.
+
+Started from p = 0 (2dvof.py:67, fields are zero-initialised), the pressure iteration
+(2dvof.py:258-266, ten sweeps per step, :521-522) sends a decaying front across the grid: behind the
+ordinary values comes a band where p walks down through 1e-280 ... 4.9e-324 to exact zero.  There the
+kernels' exact division takes its scaled tier, k_jacobi_tb reports the (row band, tile column) cells
+where it did, and the NEXT step cuts every tile column into chunks of equal cost (tb_make_plan, the
+planner block inside k_momentum, mask sets alternating with the step parity).  Which rows a wave
+takes must never change a value.  These tests run that machinery on grids where the REAL front
+exists and several tile columns are planned -- not the synthetic ring of
+test_equal_cost_work_plan_of_the_fused_jacobi:
+
+  (i)   against the CPU oracle through the whole life of the front on a 14-tile-column grid,
+        square and rectangular cells (the SQ and the general form of k_jacobi_tb);
+  (ii)  plan on == plan off at BASELINE sizes (4096^2: 35 tile columns, 250 steps; 8192^2: 70 tile
+        columns, the two-mask-word case);
+  (iii) strips (2 and 8) == single domain while the front crosses them, every strip planning its
+        own chunks.
+"""
+import numpy as np
+import pytest
+
+from util import STATE, assert_fields_same, engine, same, diff_report
+from vof2d import halo_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_cells(p, dtype="f64"):
+    lim = 1e-280 if dtype == "f64" else 1e-25      # DivLimits<T>::lo of the kernels
+    q = p[1:-1, 1:-1]
+    return int(((np.abs(q) < lim) & (q != 0)).sum())
+
+
+@pytest.mark.parametrize("nx,ny,checkpoints", [
+    (1536, 1536, (40, 55, 70, 85, 100, 150)),      # front alive in steps ~ 40 .. 100 (tiny cells: 36 000 at step 70)
+    (1024, 2304, (40, 60, 80, 110)),               # rectangular cells: k_jacobi_tb<..., SQ = false>
+])
+def test_real_front_matches_oracle(hip_api, oracle_api, nx, ny, checkpoints):
+    """(i) dam-break, fp64: all four state fields == oracle at checkpoints before, inside and after the
+    front; the equal-cost plan was in use on the way; switching it off gives the same numbers."""
+    a = engine(hip_api, nx, ny, "f64", "f32", ic=1)
+    a0 = engine(hip_api, nx, ny, "f64", "f32", ic=1)
+    a0.set_param("jacobi_tb_adapt", 0)
+    b = engine(oracle_api, nx, ny, "f64", "f32", ic=1)
+    active, tiny = [], []
+    for st in checkpoints:
+        while a.istep < st:
+            a.step(1)
+            active.append(a.get_counter("tb_plan_active"))
+        a0.step(st - a0.istep)
+        b.step(st - b.istep)
+        assert_fields_same(a, b, STATE, ctx="%dx%d plan on vs oracle, step %d" % (nx, ny, st))
+        assert_fields_same(a0, b, STATE, ctx="%dx%d plan off vs oracle, step %d" % (nx, ny, st))
+        assert a.get_counter("courant_violations") == b.get_counter("courant_violations")
+        tiny.append(_tiny_cells(b.get("p")))
+    assert a0.get_counter("tb_plan_active") == 0
+    assert max(tiny) > 1000, tiny                   # the front really was there ...
+    assert sum(1 for x in active if x) >= 20, (sum(active), len(active))   # ... and the plan really ran
+
+
+@pytest.mark.parametrize("n,steps,checks,dt", [
+    (4096, 250, (70, 130, 250), None),              # BASELINE configs[2]: 35 tile columns
+    (8192, 120, (60, 120), 1e-6),                   # configs[3] on one GPU: 70 tile columns (dt: DESIGN section 4)
+])
+def test_plan_on_equals_plan_off_at_baseline_sizes(hip_api, n, steps, checks, dt):
+    """(ii) the same run with and without the work plan, value for value, at the sizes the bench runs."""
+    kw = {} if dt is None else {"dt": dt}
+    on = engine(hip_api, n, n, "f64", "f32", ic=1, **kw)
+    off = engine(hip_api, n, n, "f64", "f32", ic=1, **kw)
+    off.set_param("jacobi_tb_adapt", 0)
+    active = 0
+    for st in checks:
+        while on.istep < st:
+            k = min(10, st - on.istep)
+            on.step(k)
+            active += on.get_counter("tb_plan_active")
+        off.step(st - off.istep)
+        for f in STATE:                              # one field at a time: 537 MB each at 8192^2
+            x, y = on.get(f), off.get(f)
+            assert same(x, y), "step %d: %s" % (st, diff_report(x, y, f))
+            if f == "p":
+                assert _tiny_cells(x) > 10000, "no tiny-value front at step %d" % st
+            del x, y
+    assert active >= len(checks) and off.get_counter("tb_plan_active") == 0
+    F = on.get("F")
+    assert F.min() >= 0.0 and F.max() <= 1.0 and on.get_counter("courant_violations") == 0
+
+
+@pytest.mark.parametrize("nstrips", [2, 8])
+def test_strips_inside_the_front(hip_api, nstrips):
+    """(iii) 2048^2 fp64 dam-break: strips with VOF_HALO_ROWS-deep halos refreshed once per step
+    (device copies stand in for RCCL send/recv) equal the single domain on their owned rows while the
+    tiny-value front crosses them; each strip plans its own chunks from its own reports."""
+    from vof2d.strips import partition, stored_rows
+    n, W = 2048, halo_rows(10)
+    full = engine(hip_api, n, n, "f64", "f32", ic=1)
+    owns = partition(n, nstrips)
+    strips = [engine(hip_api, n, n, "f64", "f32", ic=1, rows=stored_rows(n, o, W), own=o) for o in owns]
+    planned = [0] * nstrips
+    for step in range(1, 121):
+        full.step(1)
+        for s in strips:
+            s.step(1)
+        for k in range(nstrips - 1):
+            lo_s, hi_s = strips[k], strips[k + 1]
+            edge = owns[k][1]
+            for f in STATE:
+                lo_s.copy_rows_from(hi_s, f, edge + 1, edge + W)
+                hi_s.copy_rows_from(lo_s, f, edge + 1 - W, edge)
+        for k, s in enumerate(strips):
+            planned[k] += s.get_counter("tb_plan_active")
+        if step in (50, 80, 120):
+            assert _tiny_cells(full.get("p")) > 10000
+            for k, s in enumerate(strips):
+                g0 = 0 if k == 0 else owns[k][0]
+                g1 = n + 1 if k == nstrips - 1 else owns[k][1]
+                assert_fields_same(s, full, STATE, rows=(g0, g1), ctx="step %d strip %d of %d" % (step, k, nstrips))
+    assert full.get_counter("tb_plan_active") == 1
+    assert sum(1 for x in planned if x > 10) >= nstrips // 2, planned     # most strips met the front and planned
+    assert sum(s.get_counter("courant_violations") for s in strips) == full.get_counter("courant_violations")

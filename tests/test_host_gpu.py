@@ -127,3 +127,43 @@ def test_command_line_residual_terminated_solve(tmp_path):
     assert r.returncode == 0, r.stderr
     assert ">>> Grid resolution: 96 x 64, dt = 4.00e-06" in r.stdout
     assert ">>> Number of steps:100  , Time:4.00e-04 sec. Displaying VOF field." in r.stdout
+
+
+def _cli(tmp, *argv, timeout=600):
+    os.makedirs(tmp, exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "2dvof.py")] + [str(a) for a in argv], cwd=tmp,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return r.stdout
+
+
+def test_command_line_gpus_jacobi_iters_checkpoint_resume(tmp_path, oracle_api):
+    """2dvof.py --gpus 1 --jacobi-iters N --save-every / --resume on the HIP library: the checkpoints equal
+    the oracle's state, a resumed run reaches the same final state as the uninterrupted one, and the
+    PNG of the run is byte-identical either way (2dvof.py:500-501, :521, :563-571)."""
+    base = ["-ic", "1", "-s", "--gpus", "1", "--nx", "96", "--ny", "64", "--dtype", "f64", "--jacobi-iters", "12",
+            "--save-every", "70", "--steps", "210"]
+    out = _cli(tmp_path / "a", *base)
+    assert ">>> Grid resolution: 96 x 64, dt = 4.00e-06" in out and "row strips" not in out
+    _cli(tmp_path / "b", *base, "--resume", tmp_path / "a" / "data" / "00000070.npz")
+    ref = engine(oracle_api, 96, 64, "f64", "f32", ic=1, jacobi_iters=12)
+    for st in (70, 140, 210):
+        ref.step(st - ref.istep)
+        za = np.load(tmp_path / "a" / "data" / ("%08d.npz" % st))
+        for f in ("F", "u", "v", "p"):
+            assert same(za[f], ref.get(f)), diff_report(za[f], ref.get(f), "%s at step %d" % (f, st))
+            if st > 70:
+                zb = np.load(tmp_path / "b" / "data" / ("%08d.npz" % st))
+                assert same(za[f], zb[f]), diff_report(za[f], zb[f], "%s resumed, step %d" % (f, st))
+    for k in (0, 1):
+        pa = (tmp_path / "a" / "output" / ("%06d-f.png" % k)).read_bytes()
+        if k == 1:
+            assert pa == (tmp_path / "b" / "output" / ("%06d-f.png" % k)).read_bytes()
+
+
+def test_display_path_matches_reference_run(hip_api):
+    """The display kernels (2dvof.py:458-492) and the arrow list of flow_visualization.py:35-55 against what
+    the reference's own text produced when its event loop was fed SPACE releases (ref_*_vis.npz)."""
+    import test_ref_golden as trg
+    for name in trg.VIS_CASES:
+        trg.check_display_path(hip_api, name, "HIP")
