@@ -84,17 +84,22 @@ def parse():
     return ap.parse_args()
 
 
-def load_pmc_traffic(nx, ny, dtype):
+def load_pmc_traffic(nx, ny, dtype, path=None):
     """HBM bytes per Jacobi launch from the committed rocprofv3 --pmc passes (profiles/jacobi_pmc.json,
-    written by tools/summarize_profiles.py) if they were taken at this workload; {} otherwise."""
-    path = os.path.join(ROOT, "profiles", "jacobi_pmc.json")
+    written by tools/summarize_profiles.py) -- only if they were taken at this workload AND on the
+    kernel sources this library was built from (the file records their hash); otherwise nothing is
+    quoted and the reason is reported as `traffic_note`.  Returns (bytes per launch by kernel, note)."""
+    path = path or os.path.join(ROOT, "profiles", "jacobi_pmc.json")
     try:
         rec = json.load(open(path))
-        if (rec["nx"], rec["ny"], rec["dtype"]) == (nx, ny, dtype) and isinstance(rec["hbm_bytes_per_launch"], dict):
-            return rec["hbm_bytes_per_launch"]
     except Exception:
-        pass
-    return {}
+        return {}, "no committed PMC profile"
+    if (rec.get("nx"), rec.get("ny"), rec.get("dtype")) != (nx, ny, dtype) or not isinstance(rec.get("hbm_bytes_per_launch"), dict):
+        return {}, "the committed PMC profile (%s) is of another workload" % rec.get("tag")
+    from vof2d._lib import kernel_source_hash
+    if rec.get("kernel_source_sha256") != kernel_source_hash():
+        return {}, "the committed PMC profile (%s) was taken on other kernel sources: re-run tools/summarize_profiles.py" % rec.get("tag")
+    return rec["hbm_bytes_per_launch"], "rocprofv3 --pmc passes of profile %s (same kernel sources, same workload), not this run" % rec.get("tag")
 
 
 def usable_cores():
@@ -590,7 +595,7 @@ def main():
     eng.set_param("jacobi_tb", tb)
     violations = eng.get_counter("courant_violations")
     achieved_1 = sweep_bytes / (ms_sweep_1 * 1e-3) / 1e9
-    traffic = load_pmc_traffic(nx, ny, a.dtype) if not dist_path else {}
+    traffic, traffic_note = load_pmc_traffic(nx, ny, a.dtype) if not dist_path else ({}, "N > 1")
     fused = {"kernel": "k_jacobi_tb", "sweeps_per_launch": tb, "bound": "hbm (actual traffic: lead-in rows + tile overlap)",
              "us_per_launch_back_to_back": 1e3 * ms_sweep_tb * tb, "us_per_sweep_back_to_back": 1e3 * ms_sweep_tb,
              "hbm_traffic_bytes_per_launch": traffic.get("tb")}
@@ -677,6 +682,7 @@ def main():
             # bytes per launch from the committed rocprofv3 --pmc passes (profiles/jacobi_pmc.json).
             "roofline": {"bound": "hbm", "kernel": "k_jacobi", "achieved": achieved_1, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_1 / HBM_PEAK_GBS, "traffic": traffic.get("single"),
+                         "traffic_note": traffic_note,
                          "us_per_launch": 1e3 * ms_sweep_1, "algorithmic_bytes_per_launch": sweep_bytes,
                          "launches_timed": max(2, a.jacobi_sweeps_timed // 2 * 2)},
             "jacobi_fused": fused,

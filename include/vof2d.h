@@ -131,7 +131,8 @@ int vof_set_istep(vof2d_handle h, int64_t istep);
  * the two norms itself.
  *   VOF_RESID_ABS:  residual = max|p_new - p|                                  over owned rows
  *   VOF_RESID_REL:  residual = max|p_new - p| / max(max|p_new|, VOF_RESID_TINY)   
- * A non-finite update (a diverged field) reads as residual = +inf and ends the solve.
+ * A non-finite update (a diverged field) reads as residual = +inf and ends the solve; that is the only
+ * way to +inf: a finite update over a tiny max|p_new| gives a relative residual clamped to DBL_MAX.
  * *residual is this handle's local value; a multi-GPU driver all-reduces the two norms of
  * vof_jacobi_sweeps_norms itself (vof2d/strips.py). */
 #define VOF_RESID_ABS 0

@@ -22,6 +22,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  Build: see oracle/Makefile (-O2 -ffp-contract=off).
  */
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -172,7 +173,10 @@ int ovof_solve_p_jacobi(vof2d_handle h, int32_t n) {
 double ovof_residual_value(double max_update, double max_p, int32_t criterion) {
   if (!(max_update < HUGE_VAL)) return HUGE_VAL;   /* inf or NaN: diverged */
   if (criterion == VOF_RESID_ABS) return max_update;
-  return max_update / (max_p > VOF_RESID_TINY ? max_p : VOF_RESID_TINY);
+  /* a finite update over a tiny (or zero) max|p_new| must not read as "diverged": the quotient is
+   * clamped to the largest finite double, so only a non-finite UPDATE ever returns +inf */
+  const double q = max_update / (max_p > VOF_RESID_TINY ? max_p : VOF_RESID_TINY);
+  return q < HUGE_VAL ? q : DBL_MAX;
 }
 /* Extension: n sweeps; max|p_new - p| and max|p_new| over owned rows of the last one. */
 int ovof_jacobi_sweeps_norms(vof2d_handle h, int32_t n, int32_t build_rhs, double* max_update, double* max_p) {

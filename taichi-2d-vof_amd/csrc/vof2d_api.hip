@@ -4,6 +4,7 @@
 // per-step launch schedule (eager or hipGraph replay) and the pitched
 // host<->device copies behind to_numpy()/from_numpy().  No CPU compute path
 // exists here: every verb is a kernel launch.
+#include <float.h>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
@@ -1247,7 +1248,10 @@ int vof_set_istep(vof2d_handle h, int64_t istep) {
 double vof_residual_value(double max_update, double max_p, int32_t criterion) {
   if (!(max_update < HUGE_VAL)) return HUGE_VAL;   /* inf or NaN: diverged */
   if (criterion == VOF_RESID_ABS) return max_update;
-  return max_update / (max_p > VOF_RESID_TINY ? max_p : VOF_RESID_TINY);
+  /* a finite update over a tiny (or zero) max|p_new| must not read as "diverged": the quotient is
+   * clamped to the largest finite double, so only a non-finite UPDATE ever returns +inf */
+  const double q = max_update / (max_p > VOF_RESID_TINY ? max_p : VOF_RESID_TINY);
+  return q < HUGE_VAL ? q : DBL_MAX;
 }
 int vof_jacobi_sweeps_norms(vof2d_handle h, int32_t n, int32_t build_rhs, double* max_update, double* max_p) {
   if (!h || !max_update || !max_p) return VOF_EINVAL;

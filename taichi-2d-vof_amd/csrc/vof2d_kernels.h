@@ -121,6 +121,19 @@ __device__ __forceinline__ T left_of(const Row<T, V>& w, int q) { return q == 0 
 template <typename T, int V>
 __device__ __forceinline__ T right_of(const Row<T, V>& w, int q) { return q == V - 1 ? w.r : w.c[q + 1]; }
 
+// XCD-contiguous block order: physical workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup
+// dispatch"; observed, not promised -- only speed depends on it) and each XCD has its own 4 MiB L2.
+// Mapped through this, XCD x works through ONE contiguous range of logical blocks, so tiles that
+// share cache lines (column overlap, halo rows) mostly share an L2.  Used by k_jacobi_tb only, whose
+// launch is one residency round: 55.5 -> 53.9 us per launch on a 1056 x 8192 strip (59.3 -> 55.4 inside
+// the tiny-value front), neutral at 4096^2 and 2048^2.  The multi-round kernels must NOT use it: their
+// blocks are dispatched in index order, and eight separate bands in flight instead of one compact band
+// cost k_momentum 17 % and k_transport 32 % (profiles/r03_ab_xcd_and_strip_chunks.log).
+__device__ __forceinline__ int xcd_contiguous_block(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 // wave -> (column tile, row chunk).  Rows [first, last] are split in chunks of R.
 template <int V>
 __device__ __forceinline__ bool wave_tile(const Geom& g, int first, int last, int R, int& j0, int& ra,
@@ -1273,7 +1286,7 @@ __global__ __launch_bounds__(256, VOF_TB_MINWAVES) void k_jacobi_tb(Geom g, Cons
   // 2..TS, plus 1 when the first sweep also takes its j-neighbours from adjacent lanes (SQ)
   constexpr int H = ((TS - 1 + (SQ ? 1 : 0) + V - 1) / V) * V;
   constexpr int STRIDE = W - 2 * H;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   // wave -> (tile column tj, rows [ra, rb]): chunks of R rows of every column, or, while the tiny-value
   // front crosses the grid, the equal-cost chunks of the step's plan (tb_make_plan)

@@ -17,6 +17,21 @@ FAST_LIB_PATH = LIB_PATH.replace("libvof2d_hip.so", "libvof2d_hip_fast.so")
 _api = None
 
 
+def kernel_source_hash():
+    """sha256 over the HIP sources of the product library (csrc/*.h, *.hip, *.inc, sorted by name).
+    Profiles that quote per-kernel hardware counters record it (profiles/jacobi_pmc.json), and
+    bench.py only repeats such a number while the sources it was measured on are the ones built."""
+    import hashlib
+    src = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".h", ".hip", ".inc")):
+            h.update(name.encode() + b"\0")
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def hip_api(fast=False):
     """Bound `_abi.Api` of libvof2d_hip.so (loaded once).
 

@@ -104,9 +104,14 @@ class EnvComm:
         # run id, but counts its restarts (stale files of the crashed attempt stay behind, unread)
         tag = "%s_%s_%s_%s" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"),
                                env.get("TORCHELASTIC_RESTART_COUNT", "0"), env.get("VOF2D_RDZV_TAG") or os.getppid())
-        base = env.get("VOF2D_RDZV_DIR") or os.path.join("/tmp", "vof2d-%d" % os.getuid())
-        self._private_dir(base)
-        self.dir = rdzv_dir or os.path.join(base, "rdzv_" + tag)
+        if rdzv_dir is not None:
+            self.dir = rdzv_dir                  # the caller's directory: only IT has to be private
+        else:
+            # VOF2D_RDZV_DIR names a PRIVATE parent directory (created 0700 if missing; refused if it
+            # is shared, e.g. /tmp itself -- see INTEGRATION.md); default /tmp/vof2d-<uid>
+            base = env.get("VOF2D_RDZV_DIR") or os.path.join("/tmp", "vof2d-%d" % os.getuid())
+            self._private_dir(base)
+            self.dir = os.path.join(base, "rdzv_" + tag)
         self._private_dir(self.dir)
         self.timeout = timeout
         self._seq = 0

@@ -18,6 +18,23 @@ def pytest_configure(config):
 ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libvof_oracle.so")
 
 
+def usable_cores():
+    """Host cores this process may use: the affinity mask capped by the cgroup CPU quota.  The GPU box
+    shows 256 logical CPUs behind a 16-CPU quota; libgomp would start 256 threads and thrash (the
+    1536^2 oracle run of test_front_regime_gpu.py: 650 s instead of 20 s)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))   # read by libgomp when the oracle library loads
+
+
 @pytest.fixture(scope="session")
 def oracle_api():
     """The CPU oracle (test infrastructure) bound through the same ctypes prototypes."""

@@ -148,3 +148,28 @@ def test_bench_watchdog_falls_back_to_the_second_carrier():
     d, err = _run_bench(["--force-dist", "--nx", "512", "--steps", "4", "--warmup", "2", "--jacobi-sweeps-timed", "20",
                          "--attempt-timeout", "8"], env={"VOF2D_BENCH_TEST_HANG": "native"})
     assert "native attempt exceeded" in err and d["value"] > 0
+
+
+def test_traffic_is_quoted_only_for_the_kernel_sources_it_was_measured_on(tmp_path):
+    """roofline.traffic comes from committed rocprofv3 --pmc passes, not from the run: bench.py repeats it
+    only while the profile's recorded hash of csrc/ equals the sources the library is built from."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from vof2d._lib import kernel_source_hash
+    rec = {"nx": 4096, "ny": 4096, "dtype": "f64", "tag": "t", "hbm_bytes_per_launch": {"single": 4.1e8, "tb": 4.9e8},
+           "kernel_source_sha256": kernel_source_hash()}
+    p = tmp_path / "pmc.json"
+    p.write_text(json.dumps(rec))
+    got, note = bench.load_pmc_traffic(4096, 4096, "f64", str(p))
+    assert got == rec["hbm_bytes_per_launch"] and "same kernel sources" in note
+    assert bench.load_pmc_traffic(2048, 4096, "f64", str(p)) == ({}, "the committed PMC profile (t) is of another workload")
+    rec["kernel_source_sha256"] = "0" * 64
+    p.write_text(json.dumps(rec))
+    got, note = bench.load_pmc_traffic(4096, 4096, "f64", str(p))
+    assert got == {} and "other kernel sources" in note
+    del rec["kernel_source_sha256"]                       # a profile from before the hash existed
+    p.write_text(json.dumps(rec))
+    assert bench.load_pmc_traffic(4096, 4096, "f64", str(p))[0] == {}
+    assert bench.load_pmc_traffic(4096, 4096, "f64", str(tmp_path / "none.json")) == ({}, "no committed PMC profile")

@@ -71,8 +71,19 @@ SHIPPED = ("ref_ic1_200_f64", "ref_ic2_200_f64", "ref_ic3_200_f64")
 RESIZED = ("ref_ic1_96x40_f64", "ref_ic2_48x80_f64", "ref_ic3_33x17_f64")
 
 
+# configs[0] of BASELINE.json (128 x 128 dam-break, 1000 steps): the reference text itself, grid literals replaced
+BASELINE0 = "ref_ic1_128x128_f64"
+# runs whose event loop was fed a SPACE release after every display (make_ref_golden.py --vis): the reference
+# walks through its five display branches (:531-559); rgb_buf / V / the gui.arrows arguments are recorded
+VIS_CASES = tuple(n for n in REF_CASES if n.endswith("_vis"))
+
+
 def test_reference_vectors_present():
-    assert set(SHIPPED) | set(RESIZED) <= set(REF_CASES)
+    assert set(SHIPPED) | set(RESIZED) | {BASELINE0} <= set(REF_CASES) and len(VIS_CASES) >= 3
+    ref = Ref(BASELINE0)
+    assert (ref.nx, ref.ny, ref.ic, ref.nsteps) == (128, 128, 1, 1000) and "F_1000" in ref.z.files
+    shas = {str(Ref(n).z["ref_sha256"]) for n in REF_CASES if "ref_sha256" in Ref(n).z.files}
+    assert len(shas) == 1 and len(shas.pop()) == 64       # the newer files say which 2dvof.py they came from
     for name in SHIPPED:
         ref = Ref(name)
         assert (ref.nx, ref.ny) == (200, 200) and ref.nsteps == 1000      # the shipped size; odd and even istep
@@ -102,6 +113,56 @@ def test_numpy_oracle_reproduces_reference_run(name):
         done = st
         for f in ALL_FIELDS:
             ref.check(getattr(s, f), f, st, "oracle (NumPy)")
+
+
+def check_display_path(api, name, who):
+    """rgb_buf after get_vof_field / get_u_field / get_v_field / get_vnorm_field, V after interp_velocity and
+    the (orig, direction) arrays plot_arrow_field handed to gui.arrows, at the 100-step marks of a --vis run."""
+    from vof2d import vis
+    ref = Ref(name)
+    e = engine(api, ref.nx, ref.ny, "f64", "f32", ic=ref.ic)
+    seen = set()
+    for st in (int(s) for s in ref.z["vis_steps"]):
+        e.step(st - e.istep)
+        opt = int(ref.z["vis_option_%d" % st])
+        seen.add(opt)
+        got = {}
+        if opt < 4:
+            got["rgb"] = e.vis_field(vis.OPTIONS[opt][1])
+        else:
+            got["V"] = e.interp_velocity()
+            got["orig"], got["direction"] = vis.arrow_field(got["V"], 4)      # arrow_spacing=4, 2dvof.py:557
+        for k, arr in got.items():
+            full, sha = "vis_%s_%d" % (k, st), "vis_%s_sha256_%d" % (k, st)
+            if full in ref.z.files:
+                assert arr.shape == ref.z[full].shape and np.array_equal(arr, ref.z[full]), \
+                    "%s: %s" % (who, diff_report(arr.reshape(arr.shape[0], -1), ref.z[full].reshape(arr.shape[0], -1), full))
+            else:
+                assert digest(arr) == str(ref.z[sha]), "%s differs from the reference's own %s" % (who, sha)
+    assert seen == {0, 1, 2, 3, 4}
+    assert int(ref.z["gui_shown"]) == ref.nsteps // 100
+
+
+@pytest.mark.parametrize("name", VIS_CASES)
+def test_oracle_display_path_matches_reference_run(oracle_api, name):
+    check_display_path(oracle_api, name, "oracle (C)")
+
+
+@pytest.mark.parametrize("name", VIS_CASES)
+def test_numpy_oracle_display_path(name):
+    import vof_oracle_np as onp
+    from vof2d import vis
+    ref = Ref(name)
+    if ref.nx * ref.ny > 5000:
+        pytest.skip("the NumPy restatement is checked on the small display runs")
+    s = onp.new_state(ref.nx, ref.ny, ref.ic, dtype=np.float64, coord_cast="f32")
+    for st in (int(x) for x in ref.z["vis_steps"]):
+        onp.step(s, st - s.istep)
+        opt = int(ref.z["vis_option_%d" % st])
+        if opt < 4:
+            assert np.array_equal(onp.vis_field(s, vis.OPTIONS[opt][1]), ref.z["vis_rgb_%d" % st]), (st, opt)
+        else:
+            assert np.array_equal(onp.interp_velocity(s), ref.z["vis_V_%d" % st])
 
 
 @pytest.mark.parametrize("name", REF_CASES)

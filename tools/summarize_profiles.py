@@ -13,6 +13,7 @@ import collections
 import csv
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -67,7 +68,10 @@ def main():
                     hbm = (2 * v["fetch_kib"] + v["write_kib"]) * 1024
                     f.write("| %s | %.0f | %.0f | %.1f | %.2f |\n" % (k, v["fetch_kib"], v["write_kib"], hbm / 1e6,
                                                                      hbm / (a.nx * a.ny * esz)))
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "taichi-2d-vof_amd"))
+        from vof2d._lib import kernel_source_hash
         rec = {"nx": a.nx, "ny": a.ny, "dtype": a.dtype, "tag": a.tag, "hbm_bytes_per_launch": {},
+               "kernel_source_sha256": kernel_source_hash(),   # bench.py quotes these numbers only for these sources
                "rule": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes", "kernels": {}}
         for k, v in agg.items():
             if "fetch_kib" in v and "write_kib" in v and "k_jacobi" in k:
