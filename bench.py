@@ -76,9 +76,9 @@ def parse():
     ap.add_argument("--no-balance", action="store_true",
                     help="N > 1 (native exchange): keep equal strips instead of re-cutting them by the measured cost of "
                          "each rank's rows (strips.balanced_partition)")
-    ap.add_argument("--overlap", type=int, default=4, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--overlap", type=int, default=4, choices=[0, 1, 3, 4],
                     help="N > 1: 0 = one exchange after the step, 1 = each field as soon as it is final, "
-                         "2 = 1 + F's edge bands first, 3 = p, u, v together after the first sweep, 4 = fused transport "
+                         "3 = p, u, v together after the first sweep, 4 = fused transport "
                          "kernel on the edge bands, all four fields in one group under the transport of the other rows "
                          "(vof_step_exchange)")
     return ap.parse_args()

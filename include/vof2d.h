@@ -113,13 +113,8 @@ int vof_step(vof2d_handle h, int64_t nsteps);
  *   phase 0 = predictor + pressure solve + set_BC(p, F)                      -> p final
  *   phase 1 = update_uv folded into the first FCT sweep + set_BC(u, v)       -> u, v final
  *   phase 2 = second FCT sweep + post_process_f + set_BC(F) on the owned rows -> F final
- * or, instead of phase 2, VOF_PHASE_TRANSPORT_EDGES (the VOF_HALO_ROWS-row bands next to a
- * strip's interior edges, final in the twin buffer of F: what the neighbours wait for) followed by
- * VOF_PHASE_TRANSPORT_REST (the remaining owned rows).  Order 0, 1, 2 or 0, 1, 3, 4; phase 0
- * increments istep.  Halo rows of F are not produced by the second sweep: they are the
- * neighbours' to send. */
-#define VOF_PHASE_TRANSPORT_EDGES 3
-#define VOF_PHASE_TRANSPORT_REST 4
+ * Order 0, 1, 2; phase 0 increments istep.  Halo rows of F are not produced by the second sweep: they
+ * are the neighbours' to send. */
 int vof_step_phase(vof2d_handle h, int32_t phase);
 int vof_get_istep(vof2d_handle h, int64_t* istep);
 int vof_set_istep(vof2d_handle h, int64_t istep);
@@ -178,12 +173,13 @@ int vof_interp_velocity(vof2d_handle h, void* dst, size_t nbytes);
 /* ---- scalars ---- */
 /* settable: sigma (sigma[None], :28-29).  readable: sigma dt dx dy dxi dyi
  * dxi2 dyi2 Lx Ly rho_l rho_g nu_l nu_g gx gy (Python-double values).
- * Schedule knobs (settable, results never change; also as VOF2D_* environment variables at
- * vof_create): jacobi_tb (sweeps fused per launch: 5, 2 or 1), jacobi_tb_rows, jacobi_tb_narrow (one column per
- * lane in the fused Jacobi kernel: 1 on thin wide strips, 2 on any grid),
- * momentum_rows, fctx_rows, fctx_corr_rows, band_rows, rows_per_wave (rows a wave marches; 0 =
- * heuristic), fuse_momentum, fuse_correct, fuse_transport (update_uv + both sweeps as one kernel on
- * full domains; readable: 1 if in effect), virtual_ghosts (no set_BC launch in steady-state steps). */
+ * Schedule knobs (settable, results never change): jacobi_tb (sweeps fused per launch: 5, 2 or 1),
+ * jacobi_tb_adapt (the equal-cost work plan of the fused Jacobi launches), jacobi_tb_general (the
+ * general-stencil form on square cells too), chunk lengths jacobi_tb_rows, momentum_rows, fctx_rows,
+ * fctx_corr_rows, band_rows, rows_per_wave (rows a wave marches; 0 = heuristic), fuse_transport
+ * (update_uv + both sweeps as one kernel on full domains; readable: 1 if in effect), virtual_ghosts
+ * (no set_BC launch in steady-state steps).  Environment: VOF2D_DEBUG (trace to stderr), VOF2D_RCCL
+ * (path of the RCCL to bind), VOF2D_XCHG_GRAPH=0 (never capture the exchange). */
 int vof_set_param(vof2d_handle h, const char* name, double value);
 int vof_get_param(vof2d_handle h, const char* name, double* value);
 /* "courant_violations": number of faces that tripped the prints at
@@ -218,11 +214,10 @@ int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep);
  *   vof_step_exchange       nsteps x [phase 0, send/recv p, phase 1, send/recv u v, phase 2,
  *                           send/recv F, join]: each field leaves as soon as it is final for the
  *                           step and travels under the remaining kernels (overlap = 1).
- *                           overlap = 0: one exchange of all four after the step; overlap = 2:
- *                           like 1 with phase 2 split (VOF_PHASE_TRANSPORT_EDGES, send/recv F,
- *                           VOF_PHASE_TRANSPORT_REST); overlap = 3: p, u, v in one group after
- *                           phase 1, F after phase 2 (one fork less); overlap = 4: update_uv and
- *                           both sweeps as ONE kernel (k_transport), first on the edge bands, then
+ *                           overlap = 0: one exchange of all four after the step; overlap = 3: p, u,
+ *                           v in one group after phase 1, F after phase 2 (one fork less); overlap = 4
+ *                           (what the drivers use): update_uv and both sweeps as ONE kernel
+ *                           (k_transport), first on the edge bands, then
  *                           send/recv p, u, v, F in one group, and the same kernel on the remaining
  *                           rows while they travel.  After the first step (RCCL connects on
  *                           first use) a step and its exchanges are one hipGraph launch; if the

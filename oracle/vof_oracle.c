@@ -254,9 +254,9 @@ int ovof_step(vof2d_handle h, int64_t nsteps) {
  * second sweep + post_process_f + F ghosts.
  * Test double for the overlapped halo exchange; ovof_step above stays the literal main loop. */
 int ovof_step_phase(vof2d_handle h, int32_t phase) {
-  if (!h || phase < 0 || phase > 4) return VOF_EINVAL;
-  if (!(phase == h->next_phase || (phase == 3 && h->next_phase == 2))) return VOF_ESTATE;
-  h->next_phase = (phase == 2 || phase == 4) ? 0 : phase + 1;
+  if (!h || phase < 0 || phase > 2) return VOF_EINVAL;
+  if (phase != h->next_phase) return VOF_ESTATE;
+  h->next_phase = phase == 2 ? 0 : phase + 1;
   const int y_first = (h->istep + (phase == 0)) % 2 == 0; /* 2dvof.py:312-318 */
   if (phase == 0) {
     h->istep += 1;
@@ -269,9 +269,6 @@ int ovof_step_phase(vof2d_handle h, int32_t phase) {
     ovof_update_uv(h);
     DISPATCH(h, set_BC_mask, 1 | 8);
     if (y_first) ovof_fct_y_sweep(h); else ovof_fct_x_sweep(h);
-  } else if (phase == 3) {
-    /* VOF_PHASE_TRANSPORT_EDGES: the HIP library produces the edge bands of the second sweep
-     * first; in-place CPU code has nothing to split, the whole sweep runs in phase 4 */
   } else {
     if (y_first) ovof_fct_x_sweep(h); else ovof_fct_y_sweep(h);
     /* post_process_f on the interior (on ghosts it is dead: the F boundary condition follows) */

@@ -1,0 +1,270 @@
+// kernels/common.h -- tile rows, streaming loads / stores, DPP neighbours, XCD block order, exact division by a lane constant
+//
+// Part of the gfx950 kernel set of the 2-D VOF hot path (see vof2d_kernels.h for the conventions:
+// reference line citations, expression order, one wave = 64*V columns marching along i).
+#pragma once
+#include "../vof2d_device.h"
+
+namespace vof {
+
+// ------------------------------------------------------------------ helpers
+// Diagnostic build only (-DVOF_WAVE_TIMES, tools/wave_balance.py): every wave of the selected kernel
+// records when it started and ended (s_memrealtime, 100 MHz), which shows how evenly a launch's
+// waves finish.  The product build compiles WaveTimer to nothing.
+#ifdef VOF_WAVE_TIMES
+__device__ unsigned long long* vof_wave_times = nullptr;  // [2 * wave] = start, [2 * wave + 1] = end
+__device__ int vof_wave_kid = -1;
+__device__ unsigned int vof_wave_cap = 0;
+struct WaveTimer {
+  unsigned long long t0;
+  unsigned int wave;
+  bool on;
+  __device__ __forceinline__ WaveTimer(int kid) {
+    on = vof_wave_times != nullptr && vof_wave_kid == kid;
+    wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    t0 = on ? wall_clock64() : 0ull;
+  }
+  __device__ __forceinline__ ~WaveTimer() {
+    if (on && (threadIdx.x & 63) == 0 && wave < vof_wave_cap) {
+      vof_wave_times[2 * wave] = t0;
+      vof_wave_times[2 * wave + 1] = wall_clock64();
+    }
+  }
+};
+#else
+struct WaveTimer { __device__ __forceinline__ WaveTimer(int) {} };
+#endif
+enum : int { WT_MOMENTUM = 0, WT_JACOBI_TB = 3, WT_FCT_X = 5, WT_FCT_Y = 6, WT_JACOBI = 2, WT_TRANSPORT = 12 };  // = KernelId of the runtime
+template <typename T, int V>
+struct Row {  // one row of a wave tile as seen by a lane: j0-1 | j0..j0+V-1 | j0+V
+  T l;
+  T c[V];
+  T r;
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void load_c(T (&c)[V], const T* __restrict__ p) {
+  Pack<T, V> k = *reinterpret_cast<const Pack<T, V>*>(p);
+#pragma unroll
+  for (int q = 0; q < V; ++q) c[q] = k.v[q];
+}
+template <typename T, int V>
+__device__ __forceinline__ void load_row(Row<T, V>& w, const T* __restrict__ p) {
+  load_c<T, V>(w.c, p);
+  w.l = p[-1];
+  w.r = p[V];
+}
+// streaming (nontemporal) forms for data touched once per launch
+template <typename T, int V>
+__device__ __forceinline__ void load_c_nt(T (&c)[V], const T* __restrict__ p) {
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  vec_t k = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(p));
+#pragma unroll
+  for (int q = 0; q < V; ++q) c[q] = k[q];
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_c_nt(T* __restrict__ p, const T (&c)[V], int j0, int jlo, int jhi) {
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  if (j0 >= jlo && j0 + V - 1 <= jhi) {
+    vec_t k;
+#pragma unroll
+    for (int q = 0; q < V; ++q) k[q] = c[q];
+    __builtin_nontemporal_store(k, reinterpret_cast<vec_t*>(p));
+  } else {
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      if (j0 + q >= jlo && j0 + q <= jhi) p[q] = c[q];
+  }
+}
+// store columns j0..j0+V-1 restricted to [jlo, jhi]
+template <typename T, int V>
+__device__ __forceinline__ void store_c(T* __restrict__ p, const T (&c)[V], int j0, int jlo, int jhi) {
+  if (j0 >= jlo && j0 + V - 1 <= jhi) {
+    Pack<T, V> k;
+#pragma unroll
+    for (int q = 0; q < V; ++q) k.v[q] = c[q];
+    *reinterpret_cast<Pack<T, V>*>(p) = k;
+  } else {
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      if (j0 + q >= jlo && j0 + q <= jhi) p[q] = c[q];
+  }
+}
+// Streaming forms: arrays that a launch reads or writes exactly once (kernel outputs, rhs, u*, v*)
+// carry the nontemporal hint, so they do not displace the row halos that vertically adjacent chunks
+// share through L2 (k_jacobi at 4096^2 fp64: 79.5 -> 73.0 us).
+template <typename T, int V>
+__device__ __forceinline__ void load_s(T (&c)[V], const T* __restrict__ p) { load_c_nt<T, V>(c, p); }
+template <typename T, int V>
+__device__ __forceinline__ void store_s(T* __restrict__ p, const T (&c)[V], int j0, int jlo, int jhi) {
+  store_c_nt<T, V>(p, c, j0, jlo, jhi);
+}
+template <typename T, int V>
+__device__ __forceinline__ T left_of(const Row<T, V>& w, int q) { return q == 0 ? w.l : w.c[q - 1]; }
+template <typename T, int V>
+__device__ __forceinline__ T right_of(const Row<T, V>& w, int q) { return q == V - 1 ? w.r : w.c[q + 1]; }
+
+// XCD-contiguous block order: physical workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup
+// dispatch"; observed, not promised -- only speed depends on it) and each XCD has its own 4 MiB L2.
+// Mapped through this, XCD x works through ONE contiguous range of logical blocks, so tiles that
+// share cache lines (column overlap, halo rows) mostly share an L2.  Used by k_jacobi_tb only, whose
+// launch is one residency round: 55.5 -> 53.9 us per launch on a 1056 x 8192 strip (59.3 -> 55.4 inside
+// the tiny-value front), neutral at 4096^2 and 2048^2.  The multi-round kernels must NOT use it: their
+// blocks are dispatched in index order, and eight separate bands in flight instead of one compact band
+// cost k_momentum 17 % and k_transport 32 % (profiles/r03_ab_xcd_and_strip_chunks.log).
+__device__ __forceinline__ int xcd_contiguous_block(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return x * q + (x < r ? x : r) + (b >> 3);
+}
+
+// wave -> (column tile, row chunk).  Rows [first, last] are split in chunks of R.
+template <int V>
+__device__ __forceinline__ bool wave_tile(const Geom& g, int first, int last, int R, int& j0, int& ra,
+                                          int& rb) {
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR: rows are wave-uniform
+  const int lane = threadIdx.x & 63;
+  const int tj = wave % g.ntj;
+  const int ch = wave / g.ntj;
+  j0 = 1 + tj * 64 * V + lane * V;
+  ra = first + ch * R;
+  rb = ra + R - 1 < last ? ra + R - 1 : last;
+  return ra <= last && j0 <= g.ny;
+}
+__device__ __forceinline__ size_t at(const Geom& g, int i, int j) {
+  return (size_t)(i - g.row_lo) * (size_t)g.pitch + (size_t)(g.col0 + j);
+}
+
+// ------------------------------------------------------------------ cross-lane neighbours (DPP)
+// lane_up(x): value of lane-1 (lane 0 keeps its own); lane_dn(x): value of lane+1 (lane 63 keeps
+// its own).  gfx9 DPP wave_shr:1 / wave_shl:1 -- a VALU move, no LDS round trip like ds_bpermute.
+__device__ __forceinline__ int dpp_up(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_dn(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ double lane_up(double x) {
+  return __hiloint2double(dpp_up(__double2hiint(x)), dpp_up(__double2loint(x)));
+}
+__device__ __forceinline__ double lane_dn(double x) {
+  return __hiloint2double(dpp_dn(__double2hiint(x)), dpp_dn(__double2loint(x)));
+}
+__device__ __forceinline__ float lane_up(float x) { return __int_as_float(dpp_up(__float_as_int(x))); }
+__device__ __forceinline__ float lane_dn(float x) { return __int_as_float(dpp_dn(__float_as_int(x))); }
+// Zero-filling forms (bound_ctrl): lane 0 / lane 63 receive 0 instead of keeping their own value,
+// which lets the move read its source register directly (no copy first).  For kernels whose tile
+// edge columns are recomputed by the neighbouring tile anyway.
+__device__ __forceinline__ int dpp_up_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_dn_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ double lane_up_z(double x) {
+  return __hiloint2double(dpp_up_z(__double2hiint(x)), dpp_up_z(__double2loint(x)));
+}
+__device__ __forceinline__ double lane_dn_z(double x) {
+  return __hiloint2double(dpp_dn_z(__double2hiint(x)), dpp_dn_z(__double2loint(x)));
+}
+__device__ __forceinline__ float lane_up_z(float x) { return __int_as_float(dpp_up_z(__float_as_int(x))); }
+__device__ __forceinline__ float lane_dn_z(float x) { return __int_as_float(dpp_dn_z(__float_as_int(x))); }
+
+// ------------------------------------------------------------------ exact division by a lane constant
+// a / b for a denominator that is constant per lane (ap of the Jacobi stencil).  With
+// y = RN(1/b):  q = RN(a*y);  r = a - b*q (exact, one FMA);  RN(q + r*y) is the correctly rounded
+// quotient (Markstein 1990; the same final step the hardware division expansion performs after
+// its Newton iterations), i.e. bit-identical to IEEE a / b, for 3 FMA-rate ops instead of ~11.
+// Outside a safe exponent window the remainder r would underflow (tiny a) or q overflow (huge a
+// with |b| < 1).  There the numerator is scaled by an exact power of two, divided the same way and
+// the quotient Q scaled back:
+//   * tiny a (the decaying front of the Jacobi iteration walks through 1e-280 ... 4.9e-324 on its
+//     way to exact zero): Q * 2^-k is exact while the quotient is normal.  A subnormal quotient is
+//     rounded a second time by that multiplication; the two roundings differ from the single
+//     IEEE one only if Q sits exactly on a midpoint of the subnormal grid (midpoints are
+//     representable, and RN is monotonic) while the true quotient lies beside it -- the sign of
+//     the exact remainder A - b*Q tells on which side, and the tie break is undone if it went the
+//     other way;
+//   * huge a: Q * 2^k is exact or overflows to the same infinity a / b rounds to.
+// a == 0 gives the signed zero of a*y, an infinite a the infinity a*y, a NaN numerator NaN: every
+// input gets the IEEE quotient without the ~11-op hardware expansion (and without a call, which
+// would cost the register-heavy kernels their allocation).
+template <typename T> struct DivLimits;
+template <> struct DivLimits<double> {
+  static constexpr double lo = 1e-280, hi = 1e280, up = 0x1p+256, dn = 0x1p-256, qmin = 0x1p-766 /* 2^-1022 * up */,
+                          denorm_min = 0x1p-1074, half_step = 0x1p-819 /* denorm_min * up / 2 */,
+                          inf = __builtin_huge_val();
+};
+template <> struct DivLimits<float> {
+  static constexpr float lo = 1e-25f, hi = 1e25f, up = 0x1p+96f, dn = 0x1p-96f, qmin = 0x1p-30f /* 2^-126 * up */,
+                         denorm_min = 0x1p-149f, half_step = 0x1p-54f, inf = __builtin_huge_valf();
+};
+template <typename T> __device__ __forceinline__ T dfma(T a, T b, T c);
+template <> __device__ __forceinline__ double dfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float dfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ T div_scaled(T a, T b, T y, T scale) {  // RN((a * scale) / b), scale = 2^+-k
+  const T A = a * scale;
+  const T Q0 = A * y;
+  return dfma<T>(dfma<T>(-b, Q0, A), y, Q0);
+}
+
+template <typename T, bool SMALL_B = false>
+__device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
+  using L = DivLimits<T>;
+  const T q = a * y;
+  const T r = dfma<T>(-b, q, a);
+  T res = dfma<T>(r, y, q);
+  const T aa = dabs<T>(a);
+  if (aa < L::lo) {
+    res = q;                                    // a == 0: signed zero of the quotient
+    if (a != (T)0) {
+      const T Q = div_scaled<T>(a, b, y, L::up);
+      res = Q * L::dn;                          // exact if |Q| >= qmin, else RN onto the subnormal grid
+      if (!(dabs<T>(Q) >= L::qmin)) {
+        const T diff = Q - res * L::up;         // exact; +-half_step iff Q is a grid midpoint
+        const T R = dfma<T>(-b, Q, a * L::up);  // exact remainder: true quotient - Q = R / b
+        if (dabs<T>(diff) == L::half_step && R != (T)0 && ((R > (T)0) == (b > (T)0)) == (diff > (T)0))
+          res += diff > (T)0 ? L::denorm_min : -L::denorm_min;
+      }
+    }
+  } else if (SMALL_B && aa > L::hi) {
+    res = q;                                    // infinite a: the infinity a * y
+    if (aa < L::inf) res = div_scaled<T>(a, b, y, L::dn) * L::up;
+  }
+  return res;
+}
+
+// V quotients with ONE branch: all fast forms first (their instruction streams interleave), then a
+// single test whether any numerator left the fast window (tiny, zero, NaN), and only then the
+// full routine.  With a branch per quotient the compiler cannot overlap the dependent fma chains
+// of a lane's V cells.
+template <typename T, int V, bool SMALL_B = false>
+__device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], const T (&b)[V], const T (&y)[V],
+                                               int* cold = nullptr /* set to 1 when the tiny / huge tier ran */) {
+  bool odd = false;
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const T q0 = a[q] * y[q];
+    res[q] = dfma<T>(dfma<T>(-b[q], q0, a[q]), y[q], q0);
+    const T aa = dabs<T>(a[q]);
+    odd = odd || !(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi));
+  }
+  if (odd) {
+    // exact zeros (whole regions before the pressure front arrives, or away from the interface)
+    // are already right: the fast form returns the signed zero of a * y
+    bool nonzero = false;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const T aa = dabs<T>(a[q]);
+      nonzero = nonzero || (a[q] != (T)0 && (!(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi))));
+    }
+    if (nonzero) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) res[q] = div_by_const<T, SMALL_B>(a[q], b[q], y[q]);
+      if (cold) *cold = 1;
+    }
+  }
+}
+// a / b for a numerator known to lie inside the fast window (e.g. a density): no test at all
+template <typename T>
+__device__ __forceinline__ T div_by_const_inrange(T a, T b, T y) {
+  const T q0 = a * y;
+  return dfma<T>(dfma<T>(-b, q0, a), y, q0);
+}
+
+template <int N> struct IC { static constexpr int value = N; };
+
+}  // namespace vof

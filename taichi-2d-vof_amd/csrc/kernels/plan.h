@@ -1,0 +1,180 @@
+// kernels/plan.h -- the equal-cost work plan of k_jacobi_tb (tb_make_plan)
+//
+// Part of the gfx950 kernel set of the 2-D VOF hot path (see vof2d_kernels.h for the conventions:
+// reference line citations, expression order, one wave = 64*V columns marching along i).
+#pragma once
+#include "common.h"
+
+namespace vof {
+
+// ------------------------------------------------------------------ work plan of k_jacobi_tb
+// While the decaying front of the pressure iteration crosses the grid, the waves of k_jacobi_tb
+// whose rows lie in the band of tiny values (1e-280 ... 4.9e-324) execute about twice the
+// instructions per row (the exact division's scaled tier), and with one residency round per launch
+// they run on alone after the others have ended: 145 us per launch instead of 92 (4096^2).  The
+// launches therefore report WHERE the tier ran -- one bit per (row band, tile column) -- and the next
+// step cuts every tile column into chunks of equal COST instead of equal length: the same number of
+// waves, short chunks inside the band, slightly longer ones elsewhere, so that all waves end
+// together again.  Which rows a wave takes never changes a value (every cell is computed from the
+// same operands whatever the chunking; the parity tests run with the plan active).
+//   TbPlan::masks  two sets of TB_BANDS x (TB_COLS / 64) words, one bit per tile column: a step reads set (istep & 1)
+//                  -- what the previous step's launches reported -- and reports into the other, which
+//                  this step's planner clears first (its last readers were the previous step's launches)
+//   TbPlan::plan   [0] = 1 if a plan is active (else the uniform layout), [1 + wave] = the wave's
+//                  tile column and rows, packed (plan_pack)
+// The planner is one extra block -- the first -- of k_momentum's launch (the kernel in front of the
+// Jacobi launches in the fused step): it runs beside the other blocks, off the critical path.
+constexpr int TB_BANDS = 64;          // row bands of the hit masks
+constexpr int TB_COLS = 128;          // tile columns the masks cover (two 64-bit words per band): grids up to ~14 800 wide
+constexpr int TB_SLOW10 = 20;         // cost of a band row in tenths of an ordinary row
+struct TbPlan {
+  unsigned long long* masks;          // nullptr: no plan (uniform layout)
+  unsigned long long* plan;
+  int ntt, R, waves, par;             // tile columns (<= TB_COLS), uniform chunk length, waves of a launch, istep & 1
+};
+__device__ __forceinline__ unsigned long long plan_pack(int tj, int ra, int rb) {
+  return (unsigned long long)(unsigned)tj | ((unsigned long long)(unsigned)ra << 8) | ((unsigned long long)(unsigned)rb << 36);
+}
+__device__ __forceinline__ int tb_band_of(const Geom& g, int i) {   // row -> band index
+  const int rows = g.ihi - g.ilo + 1, h = (rows + TB_BANDS - 1) / TB_BANDS;
+  return (i - g.ilo) / h;
+}
+// word index of (mask set, band, tile column) and the column's bit in it
+__device__ __forceinline__ int tb_word(int set, int b, int tj) { return (set * TB_BANDS + b) * (TB_COLS / 64) + (tj >> 6); }
+// One block of 256 threads (the planner block of k_momentum's launch; it must not outlast the
+// launch's other waves, so the per-chunk work is spread over all its threads).  32-bit integers.
+struct TbPlanShared {
+  unsigned prefix[TB_COLS][TB_BANDS + 1];      // prefix[j][b] = cost of rows [0, b * bh) of tile column j, in tenths of a row
+  unsigned long long band[TB_BANDS][TB_COLS / 64];   // the reported (band, column) bits
+  int first[TB_COLS + 1];                      // first wave of column j; first[TB_COLS] = planned waves
+  int n[TB_COLS];                              // chunks of column j
+};
+__device__ __forceinline__ bool tb_bit(const TbPlanShared& sh, int b, int j) { return ((sh.band[b][j >> 6] >> (j & 63)) & 1ull) != 0ull; }
+// row position (0 .. rows) where the cumulative cost of column j reaches T
+__device__ __forceinline__ int tb_pos(const TbPlanShared& sh, int j, unsigned T, int rows, int bh) {
+  int lo = 0, hi = TB_BANDS;           // largest b with prefix[j][b] <= T
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (sh.prefix[j][mid] <= T) lo = mid; else hi = mid;
+  }
+  const bool slow = tb_bit(sh, lo, j);
+  const unsigned rest = T - sh.prefix[j][lo];
+  int pos = lo * bh + (int)(slow ? rest / (unsigned)TB_SLOW10 : rest / 10u);
+  const int bend = (lo + 1) * bh;
+  if (pos > bend) pos = bend;
+  return pos < rows ? pos : rows;
+}
+__device__ __forceinline__ int tb_wave_sum(int v) {
+  for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft, 64);
+  return v;
+}
+__device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) {
+  constexpr int CW = TB_COLS / 64;
+  const int t = threadIdx.x, lane = t & 63;
+  const int rows = g.ihi - g.ilo + 1, bh = (rows + TB_BANDS - 1) / TB_BANDS;
+  unsigned long long mine[CW];                  // band `lane` (nobody writes the read set during this step)
+  bool some = false;
+#pragma unroll
+  for (int w = 0; w < CW; ++w) {
+    mine[w] = tp.masks[tb_word(tp.par, lane, 0) + w];
+    some = some || mine[w] != 0ull;
+  }
+  const bool any = __any(some);                 // (the same in all four waves)
+  if (t < 64) {
+#pragma unroll
+    for (int w = 0; w < CW; ++w) {
+      tp.masks[tb_word(tp.par ^ 1, lane, 0) + w] = 0ull;   // this step's launches report into the other set
+      sh.band[lane][w] = mine[w];
+    }
+    if (lane == 0) tp.plan[0] = any ? 1ull : 0ull;
+  }
+  if (!any) return;                             // block-uniform
+  __syncthreads();
+  if (t < 64) {   // wave 0: per column (lane j and j + 64), the cost prefix over the bands and the number of chunks
+    unsigned cost[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int j = lane + 64 * c;
+      unsigned acc = 0;
+      for (int b = 0; b < TB_BANDS; ++b) {
+        sh.prefix[j][b] = acc;
+        const int r0 = b * bh, r1 = r0 + bh < rows ? r0 + bh : rows;
+        if (r1 > r0) acc += (unsigned)(r1 - r0) * (tb_bit(sh, b, j) ? (unsigned)TB_SLOW10 : 10u);
+      }
+      sh.prefix[j][TB_BANDS] = acc;
+      cost[c] = j < tp.ntt ? acc : 0u;
+    }
+    unsigned total = 0;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) total += (unsigned)tb_wave_sum((int)cost[c]);
+    // chunks per column, proportional to its cost (at least one), within the waves of a launch
+    const int nmax = rows >= 4 ? rows / 4 : 1;
+    int n[CW], sum = 0;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int j = lane + 64 * c;
+      n[c] = j < tp.ntt ? (int)(((unsigned long long)cost[c] * (unsigned)tp.waves) / total) : 0;
+      if (j < tp.ntt && n[c] < 1) n[c] = 1;
+      if (n[c] > nmax) n[c] = nmax;
+      sum += tb_wave_sum(n[c]);
+    }
+    // (the floor leaves a few waves over: one more for the first columns; never more than `waves`)
+    const int left = tp.waves - sum;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int j = lane + 64 * c;
+      if (left > 0 && j < tp.ntt && j < left && n[c] < nmax) n[c] += 1;
+    }
+    for (int guard = 0; guard < 8192; ++guard) {   // the at-least-one rule can overshoot on tiny grids: trim the largest
+      sum = 0;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) sum += tb_wave_sum(n[c]);
+      if (sum <= tp.waves) break;
+      int mx = 0;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) mx = n[c] > mx ? n[c] : mx;
+      for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(mx, sft, 64); mx = o > mx ? o : mx; }
+      bool done = false;                         // the first column holding the maximum gives one up
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        const unsigned long long who = __ballot(!done && n[c] == mx);
+        if (who != 0ull) {
+          if (!done && lane == __ffsll((long long)who) - 1) n[c] -= 1;
+          done = true;
+        }
+      }
+    }
+    int base = 0;   // prefix sums over the 64-column halves -> every column's first wave
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int j = lane + 64 * c;
+      int incl = n[c];
+      for (int sft = 1; sft < 64; sft <<= 1) { const int o = __shfl_up(incl, sft, 64); if (lane >= sft) incl += o; }
+      sh.n[j] = n[c];
+      sh.first[j] = base + incl - n[c];
+      base += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) sh.first[TB_COLS] = base;
+  }
+  __syncthreads();
+  const int planned = sh.first[TB_COLS];
+  for (int w = t; w < tp.waves; w += (int)blockDim.x) {
+    unsigned long long e = plan_pack(0, 1, 0);   // waves past the planned ones: empty
+    if (w < planned) {
+      int lo = 0, hi = TB_COLS;                  // the column of wave w: largest j with first[j] <= w
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sh.first[mid] <= w) lo = mid; else hi = mid;
+      }
+      const int j = lo, n = sh.n[j], k = w - sh.first[j];
+      // chunk k of column j: between the rows where the cumulative cost reaches k / n and (k + 1) / n of the column's
+      const unsigned cost = sh.prefix[j][TB_BANDS];
+      const int a = k == 0 ? 0 : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)k) / (unsigned)n), rows, bh);
+      const int b = k == n - 1 ? rows : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)(k + 1)) / (unsigned)n), rows, bh);
+      e = plan_pack(j, g.ilo + a, g.ilo + b - 1);   // (b == a: an empty chunk, the wave returns at once)
+    }
+    tp.plan[1 + w] = e;
+  }
+}
+
+}  // namespace vof

@@ -1,0 +1,298 @@
+// runtime/context.h -- field ids, constants folded like the reference does, the handle (vof2d_ctx), error helpers, chunk-length heuristics
+//
+// Part of the host-side runtime of libvof2d_hip.so; included (once, in this order) by vof2d_api.hip:
+// context.h, launches.h, schedule.h, comm.h, selftest.h.  Everything here has internal linkage.
+#pragma once
+
+#include <float.h>
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+
+#include "../../../include/vof2d.h"
+#include "../vof2d_kernels.h"
+
+using namespace vof;
+
+struct RcclId { char internal[VOF_COMM_ID_BYTES]; };  // ncclUniqueId, passed by value to ncclCommInitRank
+
+namespace {
+
+enum FieldId { fF = 0, fF2, fU, fV, fP, fPT, fUS, fVS, fMX, fMY, fKAPPA, fRHO, fNU, fRHS, NFIELDS };
+const char* const kFieldNames[NFIELDS] = {"F", "F2", "u", "v", "p", "pt", "u_star", "v_star",
+                                          "mx", "my", "kappa", "rho", "nu", "rhs"};
+
+struct ConstsD {  // Python-double values
+  double dt, dx, dy, dxi, dyi, dxi2, dyi2, rho_l, rho_g, nu_l, nu_g, sigma, gx, gy;
+  double nrm_x, nrm_y, kap_x, kap_y, dxdy, dtdy, dtdx, cfl_x, cfl_y, half_dx, half_dy, sqrt2dx, tiny;
+  double ic1_x2, ic1_y2, ic_r, ic_cx, ic2_cy, ic3_cy, ic3_pool;
+};
+
+double host_node_coord(double L, int n, int k, int cast_f32) {
+  // k-th entry of hstack((0, linspace(0, L, n+1), L)) [.astype(float32)], 2dvof.py:43-46
+  double v = k == 0 ? 0.0 : (k >= n + 1 ? L : (double)(k - 1) * (L / (double)n));
+  if (cast_f32) v = (double)(float)v;
+  return v;
+}
+
+void compute_consts(const vof2d_desc& d, ConstsD& c) {
+  const int cast = d.coord_cast_f32 || d.dtype == VOF_F32;  // an f32 field rounds the coordinates anyway
+  // 2dvof.py:47-50: Python-scope reads of x[imin+2], x[imin+1] -> Python doubles
+  const double dx = host_node_coord(d.Lx, d.nx, 3, cast) - host_node_coord(d.Lx, d.nx, 2, cast);
+  const double dy = host_node_coord(d.Ly, d.ny, 3, cast) - host_node_coord(d.Ly, d.ny, 2, cast);
+  const double dxi = 1 / dx, dyi = 1 / dy;
+  c.dt = d.dt; c.dx = dx; c.dy = dy; c.dxi = dxi; c.dyi = dyi;
+  c.dxi2 = std::pow(dxi, 2.0);  // dxi ** 2  (:216)
+  c.dyi2 = std::pow(dyi, 2.0);
+  c.rho_l = d.rho_l; c.rho_g = d.rho_g; c.nu_l = d.nu_l; c.nu_g = d.nu_g;
+  c.sigma = d.sigma; c.gx = d.gx; c.gy = d.gy;
+  c.nrm_x = -1 / (2 * dx);  // :287
+  c.nrm_y = -1 / (2 * dy);
+  c.kap_x = 1 / dx / 2;     // :308
+  c.kap_y = 1 / dy / 2;
+  c.dxdy = dx * dy;         // :324
+  c.dtdy = d.dt * dy;       // :324
+  c.dtdx = d.dt * dx;       // :388
+  c.cfl_x = 0.25 * dx;      // :274
+  c.cfl_y = 0.25 * dy;      // :279
+  c.half_dx = dx / 2;       // :105
+  c.half_dy = dy / 2;
+  c.sqrt2dx = std::sqrt(2.0) * dx;  // :131
+  c.tiny = 1e-10;           // :300
+  c.ic1_x2 = d.Lx / 3;      // :141
+  c.ic1_y2 = d.Ly / 2;      // :143
+  c.ic_r = d.Lx / 12;       // :150
+  c.ic_cx = d.Lx / 2;       // :151
+  c.ic2_cy = 2 * (d.Lx / 12);         // :151
+  c.ic3_cy = d.Ly - 3 * (d.Lx / 12);  // :155
+  c.ic3_pool = d.Ly * 0.37;           // :157
+}
+
+template <typename T>
+Consts<T> round_consts(const ConstsD& s) {
+  Consts<T> c;
+#define R1(n) c.n = (T)s.n
+  R1(dt); R1(dx); R1(dy); R1(dxi); R1(dyi); R1(dxi2); R1(dyi2); R1(rho_l); R1(rho_g); R1(nu_l); R1(nu_g);
+  R1(sigma); R1(gx); R1(gy); R1(nrm_x); R1(nrm_y); R1(kap_x); R1(kap_y); R1(dxdy); R1(dtdy); R1(dtdx);
+  R1(cfl_x); R1(cfl_y); R1(half_dx); R1(half_dy); R1(sqrt2dx); R1(tiny);
+  // RN(1/b) in T arithmetic for div_by_const
+  c.inv_dx = (T)1 / c.dx; c.inv_dy = (T)1 / c.dy; c.inv_dt = (T)1 / c.dt; c.inv_dxdy = (T)1 / c.dxdy;
+  R1(ic1_x2); R1(ic1_y2); R1(ic_r); R1(ic_cx); R1(ic2_cy); R1(ic3_cy); R1(ic3_pool);
+#undef R1
+  return c;
+}
+
+// div_by_const (vof2d_kernels.h) returns the correctly rounded a / b from y = RN(1/b) for every
+// denominator except one whose significand is all ones (Markstein).  The denominators it is used
+// with are a handful of constants; refuse the (practically impossible) bad ones at creation.
+template <typename T>
+bool all_ones_significand(T b) {
+  if (sizeof(T) == 8) {
+    uint64_t u;
+    double d = (double)b;
+    memcpy(&u, &d, 8);
+    return (u & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+  }
+  uint32_t u;
+  float f = (float)b;
+  memcpy(&u, &f, 4);
+  return (u & 0x7FFFFFu) == 0x7FFFFFu;
+}
+template <typename T>
+bool divisors_ok(const ConstsD& s) {
+  const Consts<T> c = round_consts<T>(s);
+  if (all_ones_significand(c.dx) || all_ones_significand(c.dy) || all_ones_significand(c.dt) ||
+      all_ones_significand(c.dxdy))
+    return false;
+  for (int e = 0; e <= 2; ++e)      // ap = -(ae + aw + an + as), each term present or 0 (2dvof.py:258-262)
+    for (int n = 0; n <= 2; ++n) {
+      if (e + n == 0) continue;
+      T ap = (T)0;
+      for (int k = 0; k < e; ++k) ap = ap + c.dxi2;
+      for (int k = 0; k < n; ++k) ap = ap + c.dyi2;
+      if (all_ones_significand(ap)) return false;
+    }
+  return true;
+}
+
+}  // namespace
+
+struct vof2d_ctx {
+  vof2d_desc d;
+  ConstsD cd;
+  Geom g;
+  int V;          // elements per lane
+  size_t esz;     // sizeof(T)
+  int nty;        // y-sweep tiles
+  size_t field_elems;
+  char* arena = nullptr;
+  void* fld[NFIELDS];
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int device = 0;
+  unsigned long long* d_courant = nullptr;  // device counters: [0] courant, [1] max|p_new - p| bits, [2] max|p_new| bits (residual solve)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int64_t istep = 0;
+  int rows_override = 0;
+  int tb = 5;           // Jacobi sweeps fused per launch (1 = plain kernel)
+  int tb_rows = 0;      // rows per wave chunk of the fused kernel (0 = heuristic)
+  int mom_rows = 0;     // rows per wave chunk of k_momentum (0 = heuristic)
+  int tb_general = 0;   // force the general (dx != dy) fused Jacobi kernel (tests: both forms on square cells)
+  int tb_adapt = 1;     // fused steps: shorter chunks on the tile columns the tiny-value front is crossing (k_jacobi_tb)
+  unsigned long long* d_tbmask = nullptr;  // work plan of k_jacobi_tb (TbPlan): 2 x TB_BANDS mask words, then the plan (1 + waves entries)
+  long tbplan_cap = 0;                     // waves the plan area holds
+  int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = heuristic, at most 16)
+  int fctx_corr_rows = 0;  // ... of its update_uv-carrying form (0 = same rule)
+  int fuse_transport = 1;  // vof_step on a full domain: update_uv and both FCT sweeps in one kernel (k_transport)
+  int band_rows = 4;       // rows per wave chunk of the edge-band launch of the fused transport (strips)
+  int virtual_ghosts = 1;  // ... without the step's set_BC launch (k_momentum forms the ghost cells it reads)
+  void* f_home = nullptr;  // the buffer fld[fF] pointed to at creation (orientation of the F / twin pair)
+  int phase_graph_ori = 0; // orientation the gphase / gxchg graphs were captured in
+  hipGraphExec_t gexec[2][2] = {};  // whole step, [istep parity][F in its home buffer ? 0 : 1]
+  hipGraphExec_t gphase[5] = {};  // phase 0, then phases 1, 2 x istep parity (slot 2 * phase - 1 + parity)
+  int next_phase = 0;
+  bool f_ghosts_dirty = true;  // F's ghost cells may not satisfy set_BC (after set_init_F / from_numpy / a single verb)
+  bool uv_ghosts_dirty = false; // u / v were written without a set_BC since (update_uv verb, from_numpy): their ghost cells are not mirror images
+  bool ghosts_virtual = false; // the last fused step skipped its set_BC launch: the ghost cells in memory are stale
+                               // (k_momentum forms the ones it reads; everything else goes through settle_ghosts)
+  void* vis = nullptr;      // scratch for the display fields (vof_get_vis_field / vof_interp_velocity)
+  size_t vis_bytes = 0;
+  // built-in in-situ profiler (vof_profile_steps): every launch carries a start/stop event pair
+  static constexpr int kMaxTimed = 96;
+  hipEvent_t tev[2 * kMaxTimed] = {};
+  int timed = -1;             // -1: off; otherwise launches recorded in the current batch
+  int tkid[kMaxTimed];        // kernel id of each recorded launch
+  double prof_sum_ms[16] = {};
+  long prof_cnt[16] = {};
+  std::map<const void*, long> occ_cache;  // resident waves per kernel function (resident_waves)
+  // strip halo exchange over RCCL (vof_comm_init): own communicator, stream and events
+  void* comm = nullptr;          // ncclComm_t
+  hipStream_t cstream = nullptr; // RCCL's kernels run here, next to the compute stream
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr};  // one per exchange of a step (graph capture forks)
+  hipGraphExec_t gxchg[2][5][2] = {};   // whole step + exchanges, [istep parity][overlap mode][F / twin orientation]
+  int xchg_graph = 1;                // 0 after a failed capture (or VOF2D_XCHG_GRAPH=0): eager launches
+  int64_t xchg_steps = 0;            // steps run by vof_step_exchange (the first one is always eager)
+  int64_t xchg_graph_steps = 0;      // ... of which replayed from a captured graph
+  double* d_red = nullptr;           // device scalar of vof_comm_allreduce_max
+  int comm_rank = 0, comm_world = 1;
+  int peer_lo = -1, peer_hi = -1;  // ranks owning the rows below own_lo / above own_hi (-1: wall)
+  char err[512];
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      snprintf((h)->err, sizeof((h)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call,          \
+               hipGetErrorString(e_));                                                           \
+      return VOF_EHIP;                                                                           \
+    }                                                                                            \
+  } while (0)
+
+int fail(vof2d_ctx* h, int code, const char* msg) {
+  if (h) snprintf(h->err, sizeof(h->err), "%s", msg);
+  return code;
+}
+
+int field_id(const char* name) {
+  if (!name) return -1;
+  for (int k = 0; k < NFIELDS; ++k)
+    if (!strcmp(name, kFieldNames[k])) return k;
+  return -1;
+}
+
+template <typename T> T* F_(vof2d_ctx* h, int id) { return reinterpret_cast<T*>(h->fld[id]); }
+
+// Rows per wave chunk.  Every marching kernel trades lead-in / halo rows per chunk (re-read from
+// HBM by the vertical neighbour) against the number of waves.  Two effects decide:
+//  * residency rounds: a launch whose waves exceed what the chip holds at once (occupancy x 1024
+//    SIMDs) by a little runs a nearly empty extra round (measured on k_jacobi_tb at 4096^2: 3010
+//    waves 116 us, 3080 waves 158 us), so the chunk length is chosen to make the launch k full
+//    rounds, k as small as the maximum chunk length allows;
+//  * with few cells the critical path of one wave dominates, so chunks never exceed what keeps
+//    one round's worth of waves busy (short chunks on small grids).
+// Occupancy comes from the runtime's query for the actual kernel (it depends on the compiled
+// register count); a 5 % margin absorbs the over-reporting noted in MI355X_MICROARCH.md.
+// Used for the two register-heavy, long-lived-wave kernels (k_jacobi_tb: -15 us per step at
+// 4096^2, k_momentum: -3 us); the HBM-bound kernels with short-lived waves measured best with the
+// plain cells-per-wave rule (chunk_rows) and keep it.
+template <typename K>
+long resident_waves(vof2d_ctx* h, K kernel) {
+  std::map<const void*, long>& cache = h->occ_cache;  // per handle (one host thread per handle)
+  const void* key = reinterpret_cast<const void*>(kernel);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int blocks_per_cu = 0;
+  long cap = 3L * 256 * 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) == hipSuccess && blocks_per_cu > 0) {
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    if (blocks_per_cu > 8) blocks_per_cu = 8;  // 32 waves per CU
+    cap = (long)blocks_per_cu * cus * 4;
+  } else {
+    (void)hipGetLastError();
+  }
+  cache[key] = cap;
+  return cap;
+}
+int chunk_rows_fit(const vof2d_ctx* h, int ntiles, long capacity, int rmin, int rmax) {
+  const long rows = h->g.ihi - h->g.ilo + 1;
+  const long cap = capacity * 95 / 100;
+  int R_out = rmin;
+  for (int k = 1; k <= 64; ++k) {
+    long chunks_max = k * cap / ntiles;
+    if (chunks_max < 1) continue;
+    long R = (rows + chunks_max - 1) / chunks_max;
+    if (R <= rmax) { R_out = (int)(R < rmin ? rmin : R); break; }
+  }
+  if (getenv("VOF2D_DEBUG"))
+    fprintf(stderr, "[vof2d] chunk_rows_fit: rows=%ld tiles=%d capacity=%ld -> R=%d (%ld waves)\n", rows, ntiles,
+            capacity, R_out, ((rows + R_out - 1) / R_out) * ntiles);
+  return R_out;
+}
+// cells-per-wave rule (~4096 waves, chunk length a power of two), used by the x sweep, whose 6
+// lead-in rows per chunk want long chunks (16 rows at 4096^2: 143 us; 8 rows 157 us, 4 rows 200 us)
+int chunk_rows(const vof2d_ctx* h, int ntiles, int rmin, int rmax) {
+  const long rows = h->g.ihi - h->g.ilo + 1;
+  long R = rows * ntiles / 4096;
+  if (R < rmin) R = rmin;
+  if (R > rmax) R = rmax;
+  long P = 1;
+  while (P * 2 <= R) P *= 2;
+  return (int)(P < rmin ? rmin : P);
+}
+// The streaming kernels with at most one halo row per side (single-sweep Jacobi, y sweep, the
+// per-verb kernels): very short chunks.  With the nontemporal hints on their single-use streams the
+// halo rows of vertically adjacent chunks -- consecutive blocks, resident at the same time -- are
+// L2 hits, and many short-lived waves balance better than few long ones: k_jacobi at 4096^2 fp64
+// 64 us with 2-row chunks (1 row 72 us, 4 rows 65 us, 8 rows 69 us, 32 rows 73.5 us); y sweep 112 us
+// with 1 row, 116 us with 2, 136 us with 16.
+int pick_rows(const vof2d_ctx* h, int ntiles) {
+  (void)ntiles;
+  if (h->rows_override > 0) return h->rows_override;
+  return 2;
+}
+inline unsigned blocks_rows(int rows, int ntiles, int R) {
+  const long waves = (long)((rows + R - 1) / R) * ntiles;
+  return (unsigned)((waves + 3) / 4);
+}
+inline unsigned blocks_for(const vof2d_ctx* h, int ntiles, int R) {
+  const int rows = h->g.ihi - h->g.ilo + 1;
+  const long chunks = (rows + R - 1) / R;
+  const long waves = chunks * ntiles;
+  return (unsigned)((waves + 3) / 4);
+}
+
+}  // namespace

@@ -1,0 +1,223 @@
+// runtime/launches.h -- L<T>: one launch wrapper per kernel (grid shape, chunk length, arguments), through the single launch() helper
+//
+// Part of the host-side runtime of libvof2d_hip.so; included (once, in this order) by vof2d_api.hip:
+// context.h, launches.h, schedule.h, comm.h, selftest.h.  Everything here has internal linkage.
+#pragma once
+#include "context.h"
+
+namespace {
+
+// ------------------------------------------------------------------ launches
+constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe
+enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
+                kRhs, kOther, kTransport, NKERNELS };
+const char* const kKernelNames[NKERNELS] = {"k_momentum", "k_set_bc", "k_jacobi", "k_jacobi_tb", "k_correct",
+                                            "k_fct_x", "k_fct_y", "k_normals", "k_kappa", "k_predictor", "k_rhs",
+                                            "other", "k_transport"};
+
+// One place through which every kernel is launched.  In profiling mode the dispatch carries its
+// own start/stop events (hipExtLaunchKernelGGL: the begin/end timestamps of the dispatch itself,
+// no extra barrier packets), otherwise it is a plain launch.
+template <typename... KArgs, typename... Args>
+void launch(vof2d_ctx* h, int kid, void (*kernel)(KArgs...), dim3 grid, size_t lds, Args... args) {
+  if (h->timed >= 0 && h->timed < vof2d_ctx::kMaxTimed) {
+    const int k = h->timed++;
+    h->tkid[k] = kid;
+    hipExtLaunchKernelGGL(kernel, grid, dim3(256), lds, h->stream, h->tev[2 * k], h->tev[2 * k + 1], 0, args...);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, h->stream, args...);
+  }
+}
+
+template <typename T>
+struct L {
+  static constexpr int V = VecWidth<T>::V;
+  static Consts<T> C(vof2d_ctx* h) { return round_consts<T>(h->cd); }
+
+  static void init_F(vof2d_ctx* h, int ic) {
+    dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
+    launch(h, kOther, k_init_F<T>, grid, 0, h->g, C(h), F_<T>(h, fF), F_<T>(h, fF2), ic, h->d.Lx, h->d.Ly,
+           (int)(h->d.coord_cast_f32 || h->d.dtype == VOF_F32));
+  }
+  // own_rows_only: the row loop skips the halo rows of a strip (wall ghost rows are never halo)
+  template <int MASK>
+  static void set_bc(vof2d_ctx* h, bool own_rows_only = false) {
+    const int nr = h->g.row_hi - h->g.row_lo + 1;
+    const int n = nr > h->g.ny + 2 ? nr : h->g.ny + 2;
+    const int r0 = (own_rows_only && !h->g.wall_lo) ? h->d.own_lo : h->d.row_lo;
+    const int r1 = (own_rows_only && !h->g.wall_hi) ? h->d.own_hi : h->d.row_hi;
+    launch(h, kSetBC, k_set_bc<T, MASK>, dim3((n + 255) / 256), 0, h->g, F_<T>(h, fU), F_<T>(h, fV), F_<T>(h, fF),
+           F_<T>(h, fF2), F_<T>(h, fP), F_<T>(h, fRHO), r0, r1);
+  }
+  static void bc_F_cols(vof2d_ctx* h, T* F, int r0, int r1) {
+    if (r1 < r0) return;
+    launch(h, kSetBC, k_bc_F_cols<T>, dim3((r1 - r0 + 256) / 256), 0, h->g, F, r0, r1);
+  }
+  static void nu_rho(vof2d_ctx* h) {
+    dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
+    launch(h, kOther, k_nu_rho<T>, grid, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fRHO), F_<T>(h, fNU));
+  }
+  static void post(vof2d_ctx* h) {
+    dim3 grid((h->g.ny + 2 + 255) / 256, h->g.row_hi - h->g.row_lo + 1);
+    launch(h, kOther, k_post<T>, grid, 0, h->g, F_<T>(h, fF), F_<T>(h, fF2));
+  }
+  static void normals(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    launch(h, kNormals, k_normals<T, V>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+           F_<T>(h, fMX), F_<T>(h, fMY), R);
+  }
+  static void kappa(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    launch(h, kKappa, k_kappa<T, V>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h), (const T*)F_<T>(h, fMX),
+           (const T*)F_<T>(h, fMY), F_<T>(h, fKAPPA), R);
+  }
+  template <bool STORED>
+  static void predictor(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    launch(h, kPredictor, k_predictor<T, V, STORED>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), (const T*)F_<T>(h, fKAPPA), (const T*)F_<T>(h, fF),
+           (const T*)F_<T>(h, fRHO), (const T*)F_<T>(h, fNU), F_<T>(h, fUS), F_<T>(h, fVS), R);
+  }
+  // fused normals + kappa + predictor + rhs (vof_step only)
+  static void momentum(vof2d_ctx* h, bool virt = false, int adapt_par = -1) {
+    constexpr int Wt = 64 * V, Ht = ((2 + V - 1) / V) * V, ST = Wt - 2 * Ht;
+    const int ntt = (h->g.ny + ST - 1) / ST;
+    // one residency round while that keeps the chunks short (strips, small grids); on large grids
+    // several rounds of 14-row chunks beat one round of long ones (4096^2: 184 vs 195 us, 8192^2:
+    // 665 vs 758 us) -- the halo rows of adjacent, simultaneously resident chunks are L2 hits
+    int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, resident_waves(h, k_momentum<T, V>), 4, 64);
+    if (h->mom_rows <= 0 && R > 32) R = 14;
+    const TbPlan tp = tb_plan(h, adapt_par);   // (one extra block: the planner wave)
+    launch(h, kMomentum, k_momentum<T, V>, dim3(blocks_for(h, ntt, R) + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+           (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
+           virt ? 1 : 0, tp);
+  }
+  template <bool STORED>
+  static void rhs(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    launch(h, kRhs, k_rhs<T, V, STORED>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h), (const T*)F_<T>(h, fUS),
+           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fRHO), F_<T>(h, fRHS), R);
+  }
+  // one sweep src -> dst
+  template <bool RESID>
+  static void jacobi(vof2d_ctx* h, int src, int dst) {
+    const int R = pick_rows(h, h->g.ntj);
+    launch(h, kJacobi, k_jacobi<T, V, 2, RESID>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, h->d_courant + 1);
+  }
+  // TS sweeps src -> dst in one launch, with VV columns per lane
+  template <int TS, int VV>
+  static int jacobi_tb_plan(vof2d_ctx* h, bool sq, int& ntt) {
+    constexpr int Wt = 64 * VV;
+    const int Ht = ((TS - 1 + (sq ? 1 : 0) + VV - 1) / VV) * VV, ST = Wt - 2 * Ht;  // must match the kernel
+    ntt = (h->g.ny + ST - 1) / ST;
+    const long cap = sq ? resident_waves(h, k_jacobi_tb<T, VV, TS, true, false>) : resident_waves(h, k_jacobi_tb<T, VV, TS, false, false>);
+    return h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
+  }
+  // the work plan of the step's five-sweep launches (see tb_make_plan): active on parity-keyed step
+  // sequences (adapt_par = istep & 1), square or not, two columns per lane, up to TB_COLS tile columns
+  static TbPlan tb_plan(vof2d_ctx* h, int adapt_par) {
+    TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
+    if (adapt_par < 0 || !h->tb_adapt || h->tb < 5 || h->tb_rows > 0) return tp;
+    const Consts<T> cc = C(h);
+    const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;
+    int ntt = 0;
+    const int R = jacobi_tb_plan<5, V>(h, sq, ntt);
+    const long waves = (long)blocks_for(h, ntt, R) * 4;
+    if (ntt > TB_COLS || waves > kTbPlanWaves) return tp;
+    tp.masks = h->d_tbmask;
+    tp.plan = h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64);
+    tp.ntt = ntt; tp.R = R; tp.waves = (int)waves; tp.par = adapt_par;
+    return tp;
+  }
+  template <int TS, int VV>
+  static void jacobi_tb_launch(vof2d_ctx* h, const Consts<T>& cc, bool sq, int src, int dst, int R, int ntt, int adapt_par = -1) {
+    unsigned long long* none = nullptr;
+    TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
+    if (TS == 5 && VV == V) tp = tb_plan(h, adapt_par);
+    if (sq)
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
+    else
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, false, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
+  }
+  // TS sweeps src -> dst, the last of which also reduces max|p_new - p| and max|p_new| over the owned
+  // rows into d_courant[1..2] (the residual-terminated solve): same values as
+  // jacobi_tb<TS>, same launch plan (the RESID instantiation needs a few registers more, so its
+  // own occupancy decides the chunk length)
+  template <int TS>
+  static void jacobi_tb_resid(vof2d_ctx* h, int src, int dst) {
+    const Consts<T> cc = C(h);
+    const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;
+    constexpr int Wt = 64 * V;
+    const int Ht = ((TS - 1 + (sq ? 1 : 0) + V - 1) / V) * V, ST = Wt - 2 * Ht;
+    const int ntt = (h->g.ny + ST - 1) / ST;
+    const long cap = sq ? resident_waves(h, k_jacobi_tb<T, V, TS, true, true>) : resident_waves(h, k_jacobi_tb<T, V, TS, false, true>);
+    const int R = h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
+    const TbPlan notp{nullptr, nullptr, 0, 0, 0, 0};   // uniform layout
+    if (sq)
+      launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, true, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1, notp);
+    else
+      launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, false, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1, notp);
+  }
+  template <int TS>
+  static void jacobi_tb(vof2d_ctx* h, int src, int dst, int adapt_par = -1) {
+    const Consts<T> cc = C(h);
+    const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;  // square cells: the product-carrying pipeline
+    int ntt = 0;
+    const int R = jacobi_tb_plan<TS, V>(h, sq, ntt);
+    jacobi_tb_launch<TS, V>(h, cc, sq, src, dst, R, ntt, adapt_par);
+  }
+  template <bool STORED>
+  static void correct(vof2d_ctx* h) {
+    const int R = pick_rows(h, h->g.ntj);
+    launch(h, kCorrect, k_correct<T, V, STORED>, dim3(blocks_for(h, h->g.ntj, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fP), (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fRHO), (const T*)F_<T>(h, fUS),
+           (const T*)F_<T>(h, fVS), F_<T>(h, fU), F_<T>(h, fV), R, h->d_courant);
+  }
+  // sweeps read fld[fF], write fld[fF2]; the caller swaps the two afterwards.
+  // CORR: the sweep also performs update_uv (reads u*, v*, p; writes u, v) -- see k_fct_x.
+  // rows [first, last] of the sweep's output (0, 0: all computable rows)
+  template <bool POST, bool CORR>
+  static void fct_x(vof2d_ctx* h, int first = 0, int last = 0) {
+    if (first == 0 && last == 0) { first = h->g.ilo; last = h->g.ihi; }
+    const int forced = CORR && h->fctx_corr_rows > 0 ? h->fctx_corr_rows : h->fctx_rows;
+    const int R = forced > 0 ? forced : chunk_rows(h, h->g.ntj, 4, 16);
+    launch(h, kFctX, k_fct_x<T, V, POST, CORR>, dim3(blocks_rows(last - first + 1, h->g.ntj, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fU), F_<T>(h, fF2), R, (const T*)F_<T>(h, fUS),
+           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
+  }
+  template <bool POST, bool CORR>
+  static void fct_y(vof2d_ctx* h, int first = 0, int last = 0) {
+    if (first == 0 && last == 0) { first = h->g.ilo; last = h->g.ihi; }
+    const int R = h->rows_override > 0 ? h->rows_override : 1;   // rows are independent in this sweep
+    launch(h, kFctY, k_fct_y<T, V, POST, CORR>, dim3(blocks_rows(last - first + 1, h->nty, R)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fV), F_<T>(h, fF2), R, h->nty, (const T*)F_<T>(h, fUS),
+           (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
+  }
+  // update_uv + both sweeps + post_process_f in one pass (k_transport); reads fld[fF], writes fld[fF2]
+  static int transport_rows(const vof2d_ctx* h) {
+    return h->fctx_corr_rows > 0 ? h->fctx_corr_rows : chunk_rows(h, h->nty, 4, 16);
+  }
+  static long range_chunks(const RowRanges& rr) {
+    long n = 0;
+    for (int k = 0; k < 3; ++k)
+      if (rr.last[k] >= rr.first[k]) n += (rr.last[k] - rr.first[k] + rr.R[k]) / rr.R[k];
+    return n;
+  }
+  // the rows of rr (all computable rows by default)
+  template <bool YFIRST>
+  static void transport(vof2d_ctx* h, const RowRanges* ranges = nullptr) {
+    RowRanges rr;
+    if (ranges) rr = *ranges;
+    else rr = RowRanges{{h->g.ilo, 1, 1}, {h->g.ihi, 0, 0}, {transport_rows(h), 1, 1}};
+    launch(h, kTransport, k_transport<T, V, YFIRST>, dim3((unsigned)((range_chunks(rr) * h->nty + 3) / 4)), 0, h->g, C(h),
+           (const T*)F_<T>(h, fF), F_<T>(h, fF2), h->nty, (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS),
+           (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, rr);
+  }
+};
+
+}  // namespace

@@ -1,0 +1,226 @@
+// runtime/schedule.h -- the per-step launch schedule (2dvof.py:506-528): sweeps, phases, the fused full-domain step, ghost-cell bookkeeping, graph housekeeping
+//
+// Part of the host-side runtime of libvof2d_hip.so; included (once, in this order) by vof2d_api.hip:
+// context.h, launches.h, schedule.h, comm.h, selftest.h.  Everything here has internal linkage.
+#pragma once
+#include "launches.h"
+
+namespace {
+
+void swap_F(vof2d_ctx* h) {
+  void* t = h->fld[fF];
+  h->fld[fF] = h->fld[fF2];
+  h->fld[fF2] = t;
+}
+
+template <typename T, bool POST, bool CORR = false>
+void sweep_x(vof2d_ctx* h) { L<T>::template fct_x<POST, CORR>(h); swap_F(h); }
+template <typename T, bool POST, bool CORR = false>
+void sweep_y(vof2d_ctx* h) { L<T>::template fct_y<POST, CORR>(h); swap_F(h); }
+// The second sweep of a step produces the final F.  On a strip only the owned rows are produced
+// (the halo rows are the neighbours' to send).
+template <typename T>
+void final_sweep(vof2d_ctx* h, bool along_x) {
+  const int lo = h->d.own_lo > h->g.ilo ? h->d.own_lo : h->g.ilo, hi = h->d.own_hi < h->g.ihi ? h->d.own_hi : h->g.ihi;
+  if (hi < lo) return;
+  if (along_x) L<T>::template fct_x<true, false>(h, lo, hi); else L<T>::template fct_y<true, false>(h, lo, hi);
+}
+
+enum TransportPart { kAllOwned = 0, kEdgeBands = 1, kRest = 2 };
+// The fused transport (k_transport) on the owned rows of a strip: all at once (kAllOwned), only the
+// two W-row bands at its interior edges (kEdgeBands: both in ONE launch), or only the rest (kRest).
+template <typename T>
+void transport_part(vof2d_ctx* h, bool y_first, int part) {
+  const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
+  const int lo = h->d.own_lo > h->g.ilo ? h->d.own_lo : h->g.ilo, hi = h->d.own_hi < h->g.ihi ? h->d.own_hi : h->g.ihi;
+  const bool band_lo = !h->g.wall_lo, band_hi = !h->g.wall_hi;
+  const int in_lo = band_lo ? lo + W : lo, in_hi = band_hi ? hi - W : hi;   // strips are >= W rows thick
+  const bool split = in_lo <= in_hi && (band_lo || band_hi);
+  // the bands are few rows: short chunks, so that they are many short-lived waves (2 x 16 rows of an
+  // 8192-wide strip: 31 us with 16-row chunks, 15-18 us with 4-row chunks)
+  const int Rb = h->band_rows, R = L<T>::transport_rows(h);
+  RowRanges rr{{1, 1, 1}, {0, 0, 0}, {Rb, Rb, R}};
+  if (part == kAllOwned || !split) {
+    // one range: a full domain has no bands (everything is "rest"); where the bands meet there is
+    // no rest (everything is "bands")
+    if (part == kRest && (band_lo || band_hi)) return;
+    if (part == kEdgeBands && !(band_lo || band_hi)) return;
+    rr.first[2] = lo; rr.last[2] = hi;
+  } else if (part == kEdgeBands) {
+    if (band_lo) { rr.first[0] = lo; rr.last[0] = in_lo - 1; }
+    if (band_hi) { rr.first[1] = in_hi + 1; rr.last[1] = hi; }
+  } else {
+    rr.first[2] = in_lo; rr.last[2] = in_hi;
+  }
+  if (y_first) L<T>::template transport<true>(h, &rr); else L<T>::template transport<false>(h, &rr);
+}
+
+// interior copy src -> dst (only used to keep p in place for odd sweep counts)
+template <typename T>
+__global__ void k_copy_interior(Geom g, const T* __restrict__ s, T* __restrict__ d) {
+  const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g.ilo + blockIdx.y;
+  if (j > g.ny || i > g.ihi) return;
+  const size_t o = at(g, i, j);
+  d[o] = s[o];
+}
+
+template <typename T>
+void copy_interior(vof2d_ctx* h, int src, int dst) {
+  dim3 grid((h->g.ny + 255) / 256, h->g.ihi - h->g.ilo + 1);
+  hipLaunchKernelGGL(k_copy_interior<T>, grid, dim3(256), 0, h->stream, h->g, F_<T>(h, src), F_<T>(h, dst));
+}
+
+// n Jacobi sweeps starting from fld[fP]; the result ends in fld[fP] (no pointer swap, so p's ghost
+// cells keep their set_BC values like the reference's copy-back loop :265-266).  Sweeps are grouped
+// into launches of h->tb fused sweeps (k_jacobi_tb); the remainder and the residual variant use the
+// single-sweep kernel.
+template <typename T>
+void jacobi_n(vof2d_ctx* h, int n, bool resid_last, int adapt_par = -1) {
+  if (n <= 0) return;
+  if (!(h->tb_adapt && h->tb >= 5 && !resid_last)) adapt_par = -1;
+  int cur = fP, oth = fPT;
+  auto flip = [&]() { int t = cur; cur = oth; oth = t; };
+  int left = n;
+  const int tb = h->tb;
+  // the last launch carries the norm reductions of its last sweep: a fused launch where the sweep
+  // count and the handle's fusion depth allow one, else the single-sweep kernel
+  const int last = !resid_last ? 0 : ((tb >= 5 && n >= 5) ? 5 : ((tb >= 2 && n >= 2) ? 2 : 1));
+  left -= last;
+  while (left > 0) {
+    if (tb >= 5 && left >= 5) { L<T>::template jacobi_tb<5>(h, cur, oth, adapt_par); left -= 5; }
+    else if (tb >= 2 && left >= 2) { L<T>::template jacobi_tb<2>(h, cur, oth); left -= 2; }
+    else { L<T>::template jacobi<false>(h, cur, oth); left -= 1; }
+    flip();
+  }
+  if (last == 5) { L<T>::template jacobi_tb_resid<5>(h, cur, oth); flip(); }
+  else if (last == 2) { L<T>::template jacobi_tb_resid<2>(h, cur, oth); flip(); }
+  else if (last == 1) { L<T>::template jacobi<true>(h, cur, oth); flip(); }
+  if (cur != fP) copy_interior<T>(h, fPT, fP);
+}
+
+// The fused per-step schedule, 2dvof.py:506-528 (DESIGN.md "schedule"), in three phases so a
+// multi-GPU driver can ship each field's halo as soon as the field is final for the step:
+//   phase 0: predictor + pressure solve                      -> p final
+//   phase 1: velocity correction + first FCT sweep + BC(u,v) -> u, v final
+//   phase 2: second FCT sweep (+post_process_f) + BC(F)      -> F final
+// update_uv (:524) is folded into whichever FCT sweep runs first (that sweep streams F anyway and
+// needs the corrected velocity): p, F, u*, v* -> u, v does not cost its own 6-pass kernel.
+// The reference applies the full set_BC three times per step (:518, :525, :528).  Here each field
+// gets its boundary condition once, as soon as it is final for the step -- p (and F, whose ghosts
+// the sweeps read; only the first step changes them) after the Jacobi sweeps, u / v after the
+// correction, F after the transport:
+//   * :518 only rewrites ghosts that :525 rewrites again before anything reads them (p ghosts are
+//     read by the Jacobi stencil, but always multiplied by a zero coefficient);
+//   * u, v, p do not change after :525, so :528 rewrites identical values for them;
+//   * the first sweep derives the boundary values of u, v it needs itself (corrected_velocity), and
+//     writes them where the second sweep reads them.
+// After every phase the ghost cells of the fields final so far hold exactly what the reference's
+// calls leave there, and an in-flight halo receive of a field never overlaps a kernel that writes
+// the same field.  vof_step on one handle is the three phases back to back; with merge_bc the
+// u, v boundary condition moves behind the second sweep and shares F's launch (full domains only:
+// a strip driver wants u, v complete before it ships them).
+// lean: no boundary launch inside the phases -- the caller applies set_bc<u,v,F,p> once, after the
+// second sweep (and after the halo exchange of a strip).  Valid on a step that starts with F's
+// ghost cells already consistent (every step but the first after set_init_F / from_numpy / a
+// single verb): p's ghosts only ever feed values the wall conditions override (u[1] = 0, v[:,1] =
+// 0) or zero stencil coefficients, and the first sweep itself stores the wall-face zeros of u, v
+// the second sweep reads.
+template <typename T>
+void enqueue_phase(vof2d_ctx* h, int phase, int64_t istep, bool merge_bc = false, bool lean = false, bool virt = false,
+                   int adapt_par = -1 /* istep & 1 when the caller's launch sequence is keyed by the step parity */) {
+  const bool y_first = (istep % 2 == 0);    // :526, :312-318
+  if (phase == 0) {
+    // cal_nu_rho (:513) is folded into its consumers: rho/nu = f(F[i,j]) recomputed per cell;
+    // :514, :517 and the (sweep-invariant, BC-independent) rhs of :239-241 in one pass
+    L<T>::momentum(h, virt, adapt_par);     // virt: the previous step's set_BC launch was left out (see enqueue_step)
+    jacobi_n<T>(h, h->d.jacobi_iters, false, adapt_par);  // :521-522
+    if (!lean) L<T>::template set_bc<BC_P | BC_F>(h);  // p part of :525 / :528; F part of :518 (first step)
+  } else if (phase == 1) {
+    // :524 inside the first sweep of :526
+    if (y_first) sweep_y<T, false, true>(h); else sweep_x<T, false, true>(h);
+    if (!merge_bc && !lean) L<T>::template set_bc<BC_UV>(h);  // u, v part of :525
+  } else {
+    final_sweep<T>(h, /*along_x=*/y_first);  // second sweep, :527 fused, on the owned rows
+    swap_F(h);
+    if (lean) return;                       // the caller's single set_bc<u,v,F,p> follows
+    // F part of :528 on the rows this handle produced; a strip's halo rows arrive with the
+    // sender's ghost columns (and may be arriving right now)
+    if (merge_bc) L<T>::template set_bc<BC_UV | BC_F>(h);
+    else L<T>::template set_bc<BC_F>(h, /*own_rows_only=*/true);
+  }
+}
+template <typename T>
+void enqueue_step(vof2d_ctx* h, int64_t istep, bool lean = false, bool virt = false) {
+  const bool full = h->g.wall_lo && h->g.wall_hi;
+  if (lean && full && h->fuse_transport) {
+    // :524 + :526-527 as ONE kernel: the first sweep's F never goes to memory.  One swap of the
+    // F / twin pair per step (the two-kernel form swaps twice).
+    // With virtual ghosts the step's one set_BC launch goes as well: after it, the only reader of
+    // ghost cells is the next step's k_momentum (the sweeps meet F's ghosts only at faces whose
+    // wall velocity is zero, update_uv overwrites what p's ghosts would enter, the Jacobi stencil
+    // multiplies them by zero coefficients), and that kernel forms them from the interior cells
+    // itself.  Whoever else looks at the fields goes through settle_ghosts first.
+    L<T>::momentum(h, virt, (int)(istep & 1));
+    jacobi_n<T>(h, h->d.jacobi_iters, false, (int)(istep & 1));
+    if (istep % 2 == 0) L<T>::template transport<true>(h); else L<T>::template transport<false>(h);
+    swap_F(h);
+    if (!virt) L<T>::template set_bc<BC_ALL>(h);
+    return;
+  }
+  for (int ph = 0; ph < 3; ++ph) enqueue_phase<T>(h, ph, istep, full, lean, false, (int)(istep & 1));
+  if (lean) L<T>::template set_bc<BC_ALL>(h);   // :518, :525, :528 in one launch
+}
+
+int ensure_ok(vof2d_ctx* h) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(h->err, sizeof(h->err), "kernel launch failed: %s", hipGetErrorString(e));
+    return VOF_EHIP;
+  }
+  return VOF_OK;
+}
+
+#define DISPATCH_T(h, expr_d, expr_f) \
+  do { if ((h)->d.dtype == VOF_F64) { expr_d; } else { expr_f; } } while (0)
+
+// true if the next vof_step runs the fused full-domain schedule (k_momentum, 2 x k_jacobi_tb,
+// k_transport) that leaves the ghost cells virtual
+bool step_leaves_ghosts_virtual(const vof2d_ctx* h) {
+  return h->g.wall_lo && h->g.wall_hi && h->fuse_transport &&
+         h->virtual_ghosts && !h->f_ghosts_dirty && !h->uv_ghosts_dirty;
+}
+// Every entry point that reads or writes fields other than through the fused step calls this
+// first: if the last step skipped its set_BC launch, run it now (u, v, F with its twin, p).
+void settle_ghosts(vof2d_ctx* h) {
+  if (!h->ghosts_virtual) return;
+  DISPATCH_T(h, L<double>::set_bc<BC_ALL>(h), L<float>::set_bc<BC_ALL>(h));
+  h->ghosts_virtual = false;
+}
+
+int copy_rows_host(vof2d_ctx* h, int id, int g0, int g1, void* host, size_t nbytes, bool to_host) {
+  if (g0 < h->d.row_lo || g1 > h->d.row_hi || g1 < g0) return fail(h, VOF_EINVAL, "row range not stored by this handle");
+  const size_t width = (size_t)(h->g.ny + 2) * h->esz;
+  const size_t rows = (size_t)(g1 - g0 + 1);
+  if (nbytes != width * rows) return fail(h, VOF_EINVAL, "buffer size does not match (rows, ny+2) of the field dtype");
+  char* dev = reinterpret_cast<char*>(h->fld[id]) + ((size_t)(g0 - h->d.row_lo) * h->g.pitch + h->g.col0) * h->esz;
+  const size_t dpitch = (size_t)h->g.pitch * h->esz;
+  if (to_host)
+    HIPCHK(h, hipMemcpy2DAsync(host, width, dev, dpitch, width, rows, hipMemcpyDeviceToHost, h->stream));
+  else
+    HIPCHK(h, hipMemcpy2DAsync(dev, dpitch, host, width, width, rows, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return VOF_OK;
+}
+
+void destroy_xchg_graphs(vof2d_ctx* h);
+void destroy_graphs(vof2d_ctx* h) {
+  destroy_xchg_graphs(h);
+  for (int k = 0; k < 2; ++k)
+    for (int o = 0; o < 2; ++o)
+      if (h->gexec[k][o]) { (void)hipGraphExecDestroy(h->gexec[k][o]); h->gexec[k][o] = nullptr; }
+  for (int k = 0; k < 5; ++k)
+    if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }
+}
+
+}  // namespace

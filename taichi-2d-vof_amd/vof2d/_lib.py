@@ -18,17 +18,20 @@ _api = None
 
 
 def kernel_source_hash():
-    """sha256 over the HIP sources of the product library (csrc/*.h, *.hip, *.inc, sorted by name).
+    """sha256 over the HIP sources of the product library (csrc/, csrc/kernels/, csrc/runtime/: *.h, *.hip).
     Profiles that quote per-kernel hardware counters record it (profiles/jacobi_pmc.json), and
     bench.py only repeats such a number while the sources it was measured on are the ones built."""
     import hashlib
     src = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
     h = hashlib.sha256()
-    for name in sorted(os.listdir(src)):
-        if name.endswith((".h", ".hip", ".inc")):
-            h.update(name.encode() + b"\0")
-            with open(os.path.join(src, name), "rb") as f:
-                h.update(f.read())
+    files = []
+    for sub in ("", "kernels", "runtime"):
+        d = os.path.join(src, sub)
+        files += [os.path.join(sub, n) for n in os.listdir(d) if n.endswith((".h", ".hip", ".inc"))]
+    for rel in sorted(files):
+        h.update(rel.encode() + b"\0")
+        with open(os.path.join(src, rel), "rb") as f:
+            h.update(f.read())
     return h.hexdigest()
 
 

@@ -237,8 +237,9 @@ class Engine:
         self._ck(self.api.comm_exchange(self._h, int(mask)), "comm_exchange")
 
     def step_exchange(self, nsteps=1, overlap=1):
-        """overlap: 0 = one exchange after the step, 1 = per field as soon as final, 2 = 1 + F's edge bands
-        first, 3 = p, u, v in one group after the first sweep."""
+        """overlap: 0 = one exchange after the step, 1 = per field as soon as final, 3 = p, u, v in one
+        group after the first sweep, 4 = fused transport on the edge bands first, one group for all
+        four fields under the transport of the other rows (the drivers' default)."""
         self._ck(self.api.step_exchange(self._h, int(nsteps), int(overlap)), "step_exchange")
 
     def comm_allreduce_max(self, value):

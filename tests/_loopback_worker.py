@@ -84,7 +84,7 @@ def native_rccl_exchange_loopback(hip_api):
     # (between real neighbours they are rewritten with identical values), so rows near the edges
     # depend on timing here.  Deterministic and checked: every halo ends up holding the final
     # owned rows next to it, and rows deeper than one step's dependency cone equal the reference.
-    for mode in (1, 2, 3, 1, 2, 3, 2, 1, 4, 4, 4, 1, 4, 4, 2, 4, 3, 4):   # 4: fused transport, one F / twin swap per step
+    for mode in (1, 3, 3, 1, 1, 3, 3, 1, 4, 4, 4, 1, 4, 4, 3, 4, 3, 4):   # 4: fused transport, one F / twin swap per step
         for f in ("F", "u", "v", "p"):
             ref.set(f, e.get(f, rows), rows)
         ref.istep = e.istep

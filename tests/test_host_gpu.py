@@ -107,7 +107,7 @@ def _loopback_worker(*args):
 
 def test_native_rccl_exchange_loopback():
     """vof_comm_init / vof_comm_exchange / vof_step_exchange on one GPU with both neighbours looped
-    back to the calling rank, all five overlap modes, eager first step and captured graphs."""
+    back to the calling rank, all four overlap modes, eager first step and captured graphs."""
     _loopback_worker("modes")
 
 

@@ -252,47 +252,6 @@ def test_phased_strips_on_one_gpu(hip_api):
         assert_fields_same(b, full, STATE, rows=(mid + 1, nx + 1), ctx="step %d strip b" % step)
 
 
-@pytest.mark.parametrize("nx,nstrips", [(144, 3), (96, 2), (70, 2)])
-def test_edges_first_transport_on_one_gpu(hip_api, nx, nstrips):
-    """The schedule vof_step_exchange runs: phases 0, 1, then the second FCT sweep in two parts --
-    the halo-wide bands at the interior edges (phase 3), whose rows are copied to the neighbours
-    right away (out of the twin buffer of F, where they live until phase 4), then the rest of the
-    owned rows (phase 4).  Strips equal the single domain on their owned rows.  nx = 70: strips
-    only just thicker than two bands; strips of 48 / 35 rows with W = 16."""
-    from vof2d.strips import partition, stored_rows
-    ny, W = 40, halo_rows(10)
-    full = engine(hip_api, nx, ny, "f64", "f32", ic=1)
-    owns = partition(nx, nstrips)
-    strips = [engine(hip_api, nx, ny, "f64", "f32", ic=1, rows=stored_rows(nx, o, W), own=o) for o in owns]
-
-    def halo_copy(fields, twin=False):
-        # neighbour k+1's lower halo <- strip k's top W owned rows, and vice versa
-        for k in range(nstrips - 1):
-            lo_s, hi_s = strips[k], strips[k + 1]
-            edge = owns[k][1]
-            for f in fields:
-                if twin:   # F is final only in the buffer the host does not call "F" yet
-                    top = lo_s.get("F2", (edge - W + 1, edge)); bot = hi_s.get("F2", (edge + 1, edge + W))
-                    hi_s.set("F2", top, (edge - W + 1, edge)); lo_s.set("F2", bot, (edge + 1, edge + W))
-                else:
-                    hi_s.copy_rows_from(lo_s, f, edge - W + 1, edge)
-                    lo_s.copy_rows_from(hi_s, f, edge + 1, edge + W)
-
-    for step in range(1, 13):
-        full.step(1)
-        for e in strips: e.step_phase(0)
-        halo_copy(("p",))
-        for e in strips: e.step_phase(1)
-        halo_copy(("u", "v"))
-        for e in strips: e.step_phase(3)
-        halo_copy(("F",), twin=True)
-        for e in strips: e.step_phase(4)
-        for k, e in enumerate(strips):
-            g0 = 0 if k == 0 else owns[k][0] - W
-            g1 = nx + 1 if k == nstrips - 1 else owns[k][1] + W
-            assert_fields_same(e, full, STATE, rows=(g0, g1), ctx="step %d strip %d" % (step, k))
-
-
 def test_fp32_bubble_vs_fp64_oracle_within_mixed_precision_tolerance(hip_api, oracle_api):
     """BASELINE configs[4] in miniature (rising bubble, CSF path, fp32 on the GPU) against the fp64
     oracle.  Pointwise comparison is meaningless at cut cells (find_area's strict corner tests flip

@@ -66,8 +66,6 @@ def main():
             e.step(n)
         elif mode == "native-overlap":
             e.step_exchange(n, 1)
-        elif mode == "native-edges":
-            e.step_exchange(n, 2)
         elif mode == "native-two":
             e.step_exchange(n, 3)
         elif mode == "native-after":

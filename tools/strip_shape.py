@@ -4,8 +4,8 @@
     python tools/strip_shape.py [--n 8 --rank 3 --nx 8192 --ny 8192 --steps 30]
 
 Builds the handle rank `rank` of `n` would own (owned rows + W halo rows per interior side), runs
-the phased step under the in-library profiler (vof_profile_steps) and a wall-clock loop.  Knobs
-come from the environment (VOF2D_TB, VOF2D_TB_ROWS, VOF2D_MOM_ROWS, VOF2D_ROWS, ...)."""
+the phased step under the in-library profiler (vof_profile_steps) and a wall-clock loop.  Knobs:
+--set knob=value (vof_set_param: jacobi_tb, jacobi_tb_rows, momentum_rows, rows_per_wave, ...)."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "taichi-2d-vof_amd"))
@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--dt", type=float, default=0.0, help="default: 4e-6 up to 4096^2, 1e-6 above (stability, DESIGN.md 4)")
     ap.add_argument("--sweep", default="", help="param=v1,v2,...: wall us/step per value, 3 interleaved rounds")
     ap.add_argument("--kernel", default="", help="with --sweep: report this kernel's profiled us per launch instead of the wall time per step")
+    ap.add_argument("--set", action="append", default=[], metavar="KNOB=VALUE", help="vof_set_param before the run")
     ap.add_argument("--lib", default="", help="A/B runs: another build of the library (e.g. csrc/build/variants/libvof2d_base.so)")
     a = ap.parse_args()
     from vof2d._lib import hip_api
@@ -34,6 +35,8 @@ def main():
     rows = stored_rows(a.nx, own, _abi.halo_rows(10))
     dt = a.dt if a.dt > 0 else (4e-6 if max(a.nx, a.ny) <= 4096 else 1e-6)
     e = Engine(api, make_desc(api, a.nx, a.ny, a.dtype, "f32", rows=rows, own=own, device=0, dt=dt))
+    for kv in a.set:
+        e.set_param(kv.split("=")[0], float(kv.split("=")[1]))
     e.set_init_F(1)
     e.step(a.skip); e.sync()
     if a.sweep:
