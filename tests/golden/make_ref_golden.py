@@ -75,18 +75,77 @@ ALL_FIELDS = ("F", "Ftd", "ax", "ay", "cx", "cy", "rp", "rm", "u", "v", "u_star"
 
 # ----------------------------------------------------------------------------------------------
 # the stand-in module
+F32 = False        # --f32: the reference AS SHIPPED (default_fp = ti.f32, 2dvof.py:9), see f32_notes below
+_KERNEL_DEPTH = [0]   # > 0 while a @ti.kernel / @ti.func body runs
+
+f32_notes = """--f32 emulates Taichi's static typing with NumPy scalars:
+  * fields hold float32; inside a kernel an entry reads as np.float32, at Python scope as a Python
+    float (what ti.field.__getitem__ returns), so Python-scope constants (dx, dxi, dx*dy ...) are
+    doubles folded by Python exactly as in the reference;
+  * np.float32 (op) Python float -> float32 (NumPy's weak-scalar rule): a folded double constant is
+    rounded to f32 once, where it meets a run-time value -- Taichi's rule for captured constants;
+  * loop indices are TiInt: index arithmetic stays integer, and an index that meets a float is
+    converted to f32 first (`(i - imin) * dx`, :105-106: i32 -> f32, then an f32 multiply);
+  * a kernel-local assigned from a Python float, and the value of `a if c else b` (a run-time
+    select), are f32 (`ap`, :258-262, is an f32 sum of f32 coefficients);
+  * ti.sqrt of a run-time value is the correctly rounded f32 square root; of a Python constant,
+    math.sqrt (Taichi evaluates it in Python)."""
+
+
+def _ti_loc(v):
+    """A kernel-local variable / a run-time select holding a Python float is default_fp-typed."""
+    return np.float32(v) if (F32 and type(v) is float) else v
+
+
+class TiInt(int):
+    """A loop index (ti.i32): integer arithmetic stays TiInt; meeting a float it becomes f32 first."""
+
+    def _f(self):
+        return np.float32(int(self))
+
+    def __add__(self, o):
+        return TiInt(int(self) + o) if isinstance(o, int) else self._f() + o
+
+    def __radd__(self, o):
+        return TiInt(o + int(self)) if isinstance(o, int) else o + self._f()
+
+    def __sub__(self, o):
+        return TiInt(int(self) - o) if isinstance(o, int) else self._f() - o
+
+    def __rsub__(self, o):
+        return TiInt(o - int(self)) if isinstance(o, int) else o - self._f()
+
+    def __mul__(self, o):
+        return TiInt(int(self) * o) if isinstance(o, int) else self._f() * o
+
+    def __rmul__(self, o):
+        return TiInt(o * int(self)) if isinstance(o, int) else o * self._f()
+
+    def __floordiv__(self, o):
+        return TiInt(int(self) // o)
+
+    def __truediv__(self, o):
+        return self._f() / o
+
+
+def _idx(k):
+    return TiInt(k) if F32 else k
+
+
 class Field:
     """ti.field(float, shape): dense, zero-initialised, row-major."""
 
     def __init__(self, dtype=float, shape=()):
         shape = (shape,) if isinstance(shape, int) else tuple(shape)
-        self.a = np.zeros(shape, dtype=np.float64 if dtype is float else dtype)
+        self.a = np.zeros(shape, dtype=(np.float32 if F32 else np.float64) if dtype is float else dtype)
 
     oob_reads = 0
 
     def __getitem__(self, idx):
         if idx is None:                       # sigma[None]
-            return self.a[()]
+            return self.a[()] if (_KERNEL_DEPTH[0] or not F32) else float(self.a[()])
+        if F32 and _KERNEL_DEPTH[0] == 0:     # Python scope (dx = x[3] - x[2], :47): a Python float
+            return float(self.a[idx])
         if isinstance(idx, tuple) and len(idx) == 2 and idx[0] == self.a.shape[0]:
             # interp_velocity (:490-492) loops i up to imax+1 and reads u[i+1, j] = u[imax+2, j], one row
             # past the field: undefined in Taichi's release mode (no bounds check).  Reads as 0 here
@@ -103,7 +162,7 @@ class Field:
             self.a[idx] = val
 
     def __iter__(self):                       # ``for i, j in F`` (:453)
-        return iter(itertools.product(*(range(n) for n in self.a.shape)))
+        return iter(tuple(_idx(k) for k in t) for t in itertools.product(*(range(n) for n in self.a.shape)))
 
     @property
     def shape(self):
@@ -121,7 +180,7 @@ class IVec(tuple):
     """Index vector of ti.grouped: supports ``I // r`` (:461)."""
 
     def __floordiv__(self, r):
-        return IVec(k // r for k in self)
+        return IVec(int(k) // int(r) for k in self)
 
 
 class Vector(list):
@@ -134,8 +193,8 @@ class Vector(list):
 def ndrange(*dims):
     rs = [range(*d) if isinstance(d, tuple) else range(d) for d in dims]
     if len(rs) == 1:
-        return rs[0]
-    return itertools.product(*rs)
+        return (_idx(k) for k in rs[0])
+    return (tuple(_idx(k) for k in t) for t in itertools.product(*rs))
 
 
 def grouped(f):
@@ -188,8 +247,14 @@ class _Scoper(ast.NodeTransformer):
             return ast.copy_location(call, node)
         return node
 
+    def visit_IfExp(self, node):
+        self.generic_visit(node)
+        return ast.copy_location(ast.Call(ast.Name("__ti_loc__", ast.Load()), [node], []), node)
+
     def visit_Assign(self, node):
         node.value = self.visit(node.value)   # right-hand side first, with the names as they were
+        if all(isinstance(t, ast.Name) for t in node.targets):   # a kernel local: default_fp-typed (--f32)
+            node.value = ast.copy_location(ast.Call(ast.Name("__ti_loc__", ast.Load()), [node.value], []), node.value)
         for t in node.targets:
             if isinstance(t, ast.Name) and t.id in self.glob and isinstance(self.glob[t.id], Field):
                 self.map[t.id] = t.id + "__local"
@@ -221,8 +286,18 @@ def _scoped(fn):
     ast.increment_lineno(tree, fn.__code__.co_firstlineno - 1)
     ns = {}
     fn.__globals__["__ti_pow__"] = _ti_pow
+    fn.__globals__["__ti_loc__"] = _ti_loc
     exec(compile(tree, fn.__code__.co_filename, "exec"), fn.__globals__, ns)
-    return ns[fn.__name__]
+    body = ns[fn.__name__]
+
+    def scoped(*a, **k):
+        _KERNEL_DEPTH[0] += 1
+        try:
+            return body(*a, **k)
+        finally:
+            _KERNEL_DEPTH[0] -= 1
+    scoped.__name__ = fn.__name__
+    return scoped
 
 
 class GUI:
@@ -293,7 +368,11 @@ def make_taichi():
     ti.func = _scoped
     ti.ndrange, ti.grouped = ndrange, grouped
     ti.max, ti.min, ti.abs = _tmax, _tmin, abs
-    ti.sqrt = lambda x: math.sqrt(x) if x == x and x >= 0 else float("nan")
+    def _sqrt(x):
+        if isinstance(x, np.float32):
+            return np.sqrt(x) if x >= 0 else np.float32("nan")
+        return math.sqrt(x) if x == x and x >= 0 else float("nan")
+    ti.sqrt = _sqrt
     ti.GUI = GUI
     return ti
 
@@ -388,13 +467,17 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--grid", type=int, nargs=2, default=None, metavar=("NX", "NY"),
                     help="run the reference text with its two grid-size literals (:19-20) replaced (default: as shipped, 200 200)")
+    ap.add_argument("--f32", action="store_true",
+                    help="the reference as shipped (default_fp = ti.f32): emulate Taichi's static typing (see f32_notes)")
     ap.add_argument("--vis", action="store_true",
                     help="inject a SPACE key release after every display so the reference cycles through its five "
                          "display branches (:531-559); records rgb_buf / V / the gui.arrows arguments at the 100-step marks")
     a = ap.parse_args()
+    global F32
+    F32 = a.f32
     full = sorted(set(a.full if a.full is not None else (2, a.steps)) | {0})
     nx, ny, kept, rows, const, pngs, shown, shown_vis = run_reference(a.ic, a.steps, a.s, full, a.grid, a.vis)
-    out = {"meta": np.array([nx, ny, a.ic, 0, 1]),      # same meta as make_golden.py: f64, coord cast kept
+    out = {"meta": np.array([nx, ny, a.ic, 1 if a.f32 else 0, 1]),      # same meta as make_golden.py: dtype code (0 f64, 1 f32), coord cast kept
            "steps": np.array([s for s in full if s > 0]), "nsteps": np.array(a.steps), "F_0": kept[0]["F"],
            "const_names": np.array(sorted(const)), "const": np.array([const[k] for k in sorted(const)]),
            "pngs": np.array(pngs), "gui_shown": np.array(shown)}
@@ -419,8 +502,9 @@ def main():
     out["digest_sha256"] = np.array([r[1] for r in rows])
     out["digest_sum"] = np.array([r[2] for r in rows])
     out["digest_absmax"] = np.array([r[3] for r in rows])
-    path = a.out or os.path.join(HERE, ("ref_ic%d_200_f64.npz" % a.ic) if a.grid is None else
-                                 ("ref_ic%d_%dx%d_f64%s.npz" % (a.ic, nx, ny, "_vis" if a.vis else "")))
+    prec = "f32" if a.f32 else "f64"
+    path = a.out or os.path.join(HERE, ("ref_ic%d_200_%s.npz" % (a.ic, prec)) if a.grid is None else
+                                 ("ref_ic%d_%dx%d_%s%s.npz" % (a.ic, nx, ny, prec, "_vis" if a.vis else "")))
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

@@ -1,7 +1,9 @@
 """Vectors produced by executing the reference's own source text (tests/golden/ref_*.npz,
 made by tests/golden/make_ref_golden.py in the build container: /root/reference/2dvof.py run
-unmodified under a pure-Python stand-in for the taichi module, 200 x 200 as shipped, doubles; plus
-three runs of the same text with only its grid-size literals replaced, for rectangular cells).
+unmodified under a pure-Python stand-in for the taichi module, 200 x 200 as shipped -- in doubles, and in
+the shipped precision f32 with Taichi's static typing emulated (--f32) -- plus runs of the same text with
+only its grid-size literals replaced: rectangular cells, BASELINE configs[0] (128 x 128), and the display
+path (--vis: the event loop fed SPACE releases)).
 
 These pin the oracle -- and through it, or directly, the HIP kernels -- to the reference's text
 rather than to a reading of it: every field the reference holds (19 arrays) after steps 0..10, every
@@ -32,6 +34,7 @@ class Ref:
     def __init__(self, name):
         self.z = np.load(os.path.join(HERE, "golden", name + ".npz"))
         self.nx, self.ny, self.ic = (int(v) for v in self.z["meta"][:3])
+        self.dtype = "f32" if int(self.z["meta"][3]) == 1 else "f64"     # f32: the stand-in's --f32 typing emulation
         names = [str(n) for n in self.z["digest_names"]]
         self.sha = dict(zip(names, (str(s) for s in self.z["digest_sha256"])))
         self.sum = dict(zip(names, self.z["digest_sum"]))
@@ -53,7 +56,7 @@ class Ref:
 
 def replay(api, name, fields, who, max_step=None):
     ref = Ref(name)
-    e = engine(api, ref.nx, ref.ny, "f64", "f32", ic=ref.ic)
+    e = engine(api, ref.nx, ref.ny, ref.dtype, "f32", ic=ref.ic)
     done = 0
     for st in ref.steps:
         if max_step is not None and st > max_step:
@@ -66,6 +69,9 @@ def replay(api, name, fields, who, max_step=None):
 
 
 SHIPPED = ("ref_ic1_200_f64", "ref_ic2_200_f64", "ref_ic3_200_f64")
+# the reference exactly as shipped -- default_fp = ti.f32 (2dvof.py:9) -- under the stand-in's emulation of
+# Taichi's static typing (make_ref_golden.py --f32): the reference's own dtype, pinned by its own text
+SHIPPED_F32 = ("ref_ic1_200_f32", "ref_ic2_200_f32", "ref_ic3_200_f32")
 # the reference text with only its two grid-size literals (:19-20) replaced: rectangular cells
 # (dx != dy -- the general Jacobi stencil and the `qp = (fmax - Ftd) * dx` of the y sweep, :417), odd sizes
 RESIZED = ("ref_ic1_96x40_f64", "ref_ic2_48x80_f64", "ref_ic3_33x17_f64")
@@ -84,12 +90,16 @@ def test_reference_vectors_present():
     assert (ref.nx, ref.ny, ref.ic, ref.nsteps) == (128, 128, 1, 1000) and "F_1000" in ref.z.files
     shas = {str(Ref(n).z["ref_sha256"]) for n in REF_CASES if "ref_sha256" in Ref(n).z.files}
     assert len(shas) == 1 and len(shas.pop()) == 64       # the newer files say which 2dvof.py they came from
-    for name in SHIPPED:
+    assert set(SHIPPED_F32) <= set(REF_CASES)
+    for name in SHIPPED + SHIPPED_F32:
         ref = Ref(name)
+        assert ref.dtype == ("f32" if name in SHIPPED_F32 else "f64") and ref.z["F_1000"].dtype == (np.float32 if name in SHIPPED_F32 else np.float64)
         assert (ref.nx, ref.ny) == (200, 200) and ref.nsteps == 1000      # the shipped size; odd and even istep
         # constants the reference derived at Python scope (2dvof.py:47-50)
         c = dict(zip((str(k) for k in ref.z["const_names"]), ref.z["const"]))
-        assert c["dx"] == 0.00050000002374872565 and c["dt"] == 4e-6 and c["sigma"] == 0.007
+        # (sigma is a 0-D field, :28-29: read back at Python scope it is the stored f32 value in the f32 runs)
+        assert c["dx"] == 0.00050000002374872565 and c["dt"] == 4e-6
+        assert c["sigma"] == (float(np.float32(0.007)) if ref.dtype == "f32" else 0.007)
     for name in RESIZED:
         ref = Ref(name)
         c = dict(zip((str(k) for k in ref.z["const_names"]), ref.z["const"]))
@@ -106,7 +116,7 @@ def test_oracle_reproduces_reference_run(oracle_api, name):
 def test_numpy_oracle_reproduces_reference_run(name):
     import vof_oracle_np as onp
     ref = Ref(name)
-    s = onp.new_state(ref.nx, ref.ny, ref.ic, dtype=np.float64, coord_cast="f32")
+    s = onp.new_state(ref.nx, ref.ny, ref.ic, dtype=np.float32 if ref.dtype == "f32" else np.float64, coord_cast="f32")
     done = 0
     for st in [t for t in ref.steps if t <= 20]:
         onp.step(s, st - done)
@@ -120,7 +130,7 @@ def check_display_path(api, name, who):
     the (orig, direction) arrays plot_arrow_field handed to gui.arrows, at the 100-step marks of a --vis run."""
     from vof2d import vis
     ref = Ref(name)
-    e = engine(api, ref.nx, ref.ny, "f64", "f32", ic=ref.ic)
+    e = engine(api, ref.nx, ref.ny, ref.dtype, "f32", ic=ref.ic)
     seen = set()
     for st in (int(s) for s in ref.z["vis_steps"]):
         e.step(st - e.istep)
@@ -155,7 +165,7 @@ def test_numpy_oracle_display_path(name):
     ref = Ref(name)
     if ref.nx * ref.ny > 5000:
         pytest.skip("the NumPy restatement is checked on the small display runs")
-    s = onp.new_state(ref.nx, ref.ny, ref.ic, dtype=np.float64, coord_cast="f32")
+    s = onp.new_state(ref.nx, ref.ny, ref.ic, dtype=np.float32 if ref.dtype == "f32" else np.float64, coord_cast="f32")
     for st in (int(x) for x in ref.z["vis_steps"]):
         onp.step(s, st - s.istep)
         opt = int(ref.z["vis_option_%d" % st])
@@ -169,7 +179,7 @@ def test_numpy_oracle_display_path(name):
 def test_reference_png_and_gui_path(name):
     """-s of the reference itself (:563-571): one PNG per 100 steps, numbered from 000000."""
     ref = Ref(name)
-    if name not in SHIPPED:
+    if name not in SHIPPED + SHIPPED_F32:
         pytest.skip("-s was passed to the shipped-size runs only")
     pngs = [str(p) for p in ref.z["pngs"]]
     assert pngs == ["%06d-f.png" % k for k in range(ref.nsteps // 100)]
@@ -194,7 +204,7 @@ def test_hip_verbs_reproduce_reference_run(hip_api, name):
     """The verb-by-verb HIP path (one C-ABI call per reference kernel, 2dvof.py:513-528)."""
     from vof2d.solver import VOF2D
     ref = Ref(name)
-    s = VOF2D(ref.nx, ref.ny, dtype="f64", coord_cast="f32", api=hip_api)
+    s = VOF2D(ref.nx, ref.ny, dtype=ref.dtype, coord_cast="f32", api=hip_api)
     s.set_init_F(ref.ic)
     done = 0
     for st in [t for t in ref.steps if t <= 30]:
