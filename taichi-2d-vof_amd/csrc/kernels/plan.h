@@ -43,22 +43,37 @@ __device__ __forceinline__ int tb_band_of(const Geom& g, int i) {   // row -> ba
 __device__ __forceinline__ int tb_word(int set, int b, int tj) { return (set * TB_BANDS + b) * (TB_COLS / 64) + (tj >> 6); }
 // One block of 256 threads (the planner block of k_momentum's launch; it must not outlast the
 // launch's other waves, so the per-chunk work is spread over all its threads).  32-bit integers.
+// 3 KB of LDS: every block of the launch reserves it, so it is kept small (a per-column cost prefix
+// table, 33 KB, capped k_momentum at 4 blocks per CU; the prefix is now a closed form of the column's
+// 64 band bits, tb_prefix).
 struct TbPlanShared {
-  unsigned prefix[TB_COLS][TB_BANDS + 1];      // prefix[j][b] = cost of rows [0, b * bh) of tile column j, in tenths of a row
-  unsigned long long band[TB_BANDS][TB_COLS / 64];   // the reported (band, column) bits
+  unsigned long long band[TB_BANDS][TB_COLS / 64];   // the reported (band, column) bits, as the launches wrote them
+  unsigned long long col[TB_COLS];             // the same bits per tile column: bit b = band b of column j was reported
   int first[TB_COLS + 1];                      // first wave of column j; first[TB_COLS] = planned waves
   int n[TB_COLS];                              // chunks of column j
 };
 __device__ __forceinline__ bool tb_bit(const TbPlanShared& sh, int b, int j) { return ((sh.band[b][j >> 6] >> (j & 63)) & 1ull) != 0ull; }
+// cost of rows [0, min(b * bh, rows)) of a tile column, in tenths of a row: 10 per row, TB_SLOW10 per row of a
+// reported band.  Bands 0 .. rows / bh - 1 are bh rows long, the next one holds the remainder, the rest are empty.
+__device__ __forceinline__ unsigned tb_prefix(unsigned long long colbits, int b, int rows, int bh) {
+  const int nfull = rows / bh, part = rows - nfull * bh;       // (bh >= 1: rows >= 1 on every handle)
+  const unsigned long long upto = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+  const unsigned long long full = nfull >= 64 ? ~0ull : ((1ull << nfull) - 1ull);
+  int slow_rows = bh * __popcll(colbits & upto & full);
+  if (part > 0 && nfull < b && nfull < 64 && ((colbits >> nfull) & 1ull)) slow_rows += part;
+  const int before = b * bh < rows ? b * bh : rows;
+  return 10u * (unsigned)before + (unsigned)(TB_SLOW10 - 10) * (unsigned)slow_rows;
+}
 // row position (0 .. rows) where the cumulative cost of column j reaches T
 __device__ __forceinline__ int tb_pos(const TbPlanShared& sh, int j, unsigned T, int rows, int bh) {
-  int lo = 0, hi = TB_BANDS;           // largest b with prefix[j][b] <= T
+  const unsigned long long colbits = sh.col[j];
+  int lo = 0, hi = TB_BANDS;           // largest b with prefix(b) <= T
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (sh.prefix[j][mid] <= T) lo = mid; else hi = mid;
+    if (tb_prefix(colbits, mid, rows, bh) <= T) lo = mid; else hi = mid;
   }
-  const bool slow = tb_bit(sh, lo, j);
-  const unsigned rest = T - sh.prefix[j][lo];
+  const bool slow = ((colbits >> lo) & 1ull) != 0ull;
+  const unsigned rest = T - tb_prefix(colbits, lo, rows, bh);
   int pos = lo * bh + (int)(slow ? rest / (unsigned)TB_SLOW10 : rest / 10u);
   const int bend = (lo + 1) * bh;
   if (pos > bend) pos = bend;
@@ -95,14 +110,10 @@ __device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) 
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       const int j = lane + 64 * c;
-      unsigned acc = 0;
-      for (int b = 0; b < TB_BANDS; ++b) {
-        sh.prefix[j][b] = acc;
-        const int r0 = b * bh, r1 = r0 + bh < rows ? r0 + bh : rows;
-        if (r1 > r0) acc += (unsigned)(r1 - r0) * (tb_bit(sh, b, j) ? (unsigned)TB_SLOW10 : 10u);
-      }
-      sh.prefix[j][TB_BANDS] = acc;
-      cost[c] = j < tp.ntt ? acc : 0u;
+      unsigned long long bits = 0ull;
+      for (int b = 0; b < TB_BANDS; ++b) bits |= tb_bit(sh, b, j) ? (1ull << b) : 0ull;
+      sh.col[j] = bits;
+      cost[c] = j < tp.ntt ? tb_prefix(bits, TB_BANDS, rows, bh) : 0u;
     }
     unsigned total = 0;
 #pragma unroll
@@ -168,7 +179,7 @@ __device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) 
       }
       const int j = lo, n = sh.n[j], k = w - sh.first[j];
       // chunk k of column j: between the rows where the cumulative cost reaches k / n and (k + 1) / n of the column's
-      const unsigned cost = sh.prefix[j][TB_BANDS];
+      const unsigned cost = tb_prefix(sh.col[j], TB_BANDS, rows, bh);
       const int a = k == 0 ? 0 : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)k) / (unsigned)n), rows, bh);
       const int b = k == n - 1 ? rows : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)(k + 1)) / (unsigned)n), rows, bh);
       e = plan_pack(j, g.ilo + a, g.ilo + b - 1);   // (b == a: an empty chunk, the wave returns at once)

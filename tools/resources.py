@@ -12,7 +12,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "taichi-2d
 
 
 def remarks(extra=()):
-    srcs = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    srcs = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]   # one translation unit (vof2d_api.hip) that includes kernels/ and runtime/
     out = ""
     for s in srcs:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
