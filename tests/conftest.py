@@ -32,7 +32,10 @@ def usable_cores():
     return n
 
 
-os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))   # read by libgomp when the oracle library loads
+# read by libgomp when the oracle library loads.  Capped at 16: most oracle runs of the suite are small grids
+# whose hundreds of parallel regions per step cost more in barriers than they gain beyond that (a box
+# without a CPU quota ran the GPU suite in 590 s with 256 threads, 85 s with 16)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, usable_cores())))
 
 
 @pytest.fixture(scope="session")
