@@ -28,6 +28,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["algorithmic_bytes_per_launch"] == 3 * 8 * 512 * 512
+    assert "traffic" in rf and isinstance(rf["traffic_note"], str)
+    low = rf["in_step_lowest"]                     # the kernel of the step itself that is furthest below the peak
+    assert low["kernel"] in ("k_momentum", "k_jacobi_tb", "k_transport") and abs(low["frac_of_peak"] - low["achieved"] / 8000.0) < 1e-12
+    assert low["frac_of_peak"] == min(v["frac_of_peak"] for v in d["step_kernels"].values())
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "oracle/vof_oracle.c" in cb["sample"]
     assert "workload" in d["config"] and "model" not in d["config"]
