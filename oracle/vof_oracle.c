@@ -11,13 +11,17 @@
  * reference's test/ scripts hold no golden vectors.  This restatement is
  * pinned to the reference's own source text, executed: tests/golden/ref_*.npz
  * come from /root/reference/2dvof.py run unmodified under a pure-Python
- * stand-in for the taichi module (tests/golden/make_ref_golden.py: 200 x 200
- * as shipped, doubles, -ic 1/2/3, 1000 steps; three rectangular-cell runs with
- * only the grid-size literals replaced), and tests/test_ref_golden.py requires
- * all 19 arrays of every recorded step to be reproduced exactly.  NOT pinned:
- * Taichi's code generation (fast_math contraction / reassociation).  Also
- * checked against the independent NumPy restatement (oracle/vof_oracle_np.py)
- * and the self-generated fixtures in tests/golden/.
+ * stand-in for the taichi module (tests/golden/make_ref_golden.py): 200 x 200
+ * as shipped, -ic 1/2/3, 1000 steps, in doubles AND in the shipped precision
+ * f32 (Taichi's static typing emulated with NumPy float32 scalars); 128 x 128
+ * -ic 1 (BASELINE configs[0]); rectangular-cell runs with only the grid-size
+ * literals replaced; runs whose event loop is fed SPACE releases, recording the
+ * display buffers (2dvof.py:458-492, :531-559).  tests/test_ref_golden.py
+ * requires all 19 arrays of every recorded step -- and rgb_buf / V / the arrow
+ * list -- to be reproduced exactly, fp64 and fp32.  NOT pinned: Taichi's code
+ * generation (fast_math contraction / reassociation).  Also checked against the
+ * independent NumPy restatement (oracle/vof_oracle_np.py) and the
+ * self-generated fixtures in tests/golden/.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  Build: see oracle/Makefile (-O2 -ffp-contract=off).

@@ -227,6 +227,17 @@ __device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
   return res;
 }
 
+// fp32: |a| in (0, lo) -- a non-zero numerator below the fast window -- by one integer test on the bit
+// pattern.  Exact zeros (whole regions before the pressure front arrives, or away from the interface)
+// and NaNs are NOT in it: the fast form already returns the signed zero of a * y (or the NaN).  Measured
+// (tools/probes/README.md, round 3): -0.7 % on the 2048^2 fp32 bubble step; the fp64 analogue (two
+// dword tests instead of one half-rate v_cmp_f64 per quotient) is 3-6 % SLOWER on k_jacobi_tb<double>,
+// so fp64 keeps the floating-point test with a second-level zero check.
+__device__ __forceinline__ bool tiny_nonzero(float a) {
+  constexpr unsigned LO_BITS = __builtin_bit_cast(unsigned, DivLimits<float>::lo);
+  return ((__float_as_uint(a) & 0x7fffffffu) - 1u) < (LO_BITS - 1u);
+}
+
 // V quotients with ONE branch: all fast forms first (their instruction streams interleave), then a
 // single test whether any numerator left the fast window (tiny, zero, NaN), and only then the
 // full routine.  With a branch per quotient the compiler cannot overlap the dependent fma chains
@@ -235,26 +246,39 @@ template <typename T, int V, bool SMALL_B = false>
 __device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], const T (&b)[V], const T (&y)[V],
                                                int* cold = nullptr /* set to 1 when the tiny / huge tier ran */) {
   bool odd = false;
-#pragma unroll
-  for (int q = 0; q < V; ++q) {
-    const T q0 = a[q] * y[q];
-    res[q] = dfma<T>(dfma<T>(-b[q], q0, a[q]), y[q], q0);
-    const T aa = dabs<T>(a[q]);
-    odd = odd || !(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi));
-  }
-  if (odd) {
-    // exact zeros (whole regions before the pressure front arrives, or away from the interface)
-    // are already right: the fast form returns the signed zero of a * y
-    bool nonzero = false;
+  if constexpr (sizeof(T) == 4) {
 #pragma unroll
     for (int q = 0; q < V; ++q) {
-      const T aa = dabs<T>(a[q]);
-      nonzero = nonzero || (a[q] != (T)0 && (!(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi))));
+      const T q0 = a[q] * y[q];
+      res[q] = dfma<T>(dfma<T>(-b[q], q0, a[q]), y[q], q0);
+      odd = odd || tiny_nonzero(a[q]) || (SMALL_B && !(dabs<T>(a[q]) <= DivLimits<T>::hi));
     }
-    if (nonzero) {
+    if (odd) {   // (lanes holding a tiny non-zero or a huge / non-finite numerator only)
 #pragma unroll
       for (int q = 0; q < V; ++q) res[q] = div_by_const<T, SMALL_B>(a[q], b[q], y[q]);
       if (cold) *cold = 1;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const T q0 = a[q] * y[q];
+      res[q] = dfma<T>(dfma<T>(-b[q], q0, a[q]), y[q], q0);
+      const T aa = dabs<T>(a[q]);
+      odd = odd || !(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi));
+    }
+    if (odd) {
+      // exact zeros are already right: the fast form returns the signed zero of a * y
+      bool nonzero = false;
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const T aa = dabs<T>(a[q]);
+        nonzero = nonzero || (a[q] != (T)0 && (!(aa >= DivLimits<T>::lo) || (SMALL_B && !(aa <= DivLimits<T>::hi))));
+      }
+      if (nonzero) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) res[q] = div_by_const<T, SMALL_B>(a[q], b[q], y[q]);
+        if (cold) *cold = 1;
+      }
     }
   }
 }
