@@ -79,3 +79,24 @@ def test_flags_of_the_reference_and_refusals():
         cli.run(p.parse_args(["--gpus", "2", "--verbs"]), api=object(), rank=0, world=2)
     with pytest.raises(SystemExit):
         cli.run(p.parse_args(["--gpus", "2"]), api=object(), rank=0, world=3)
+
+
+def test_main_becomes_the_launcher_only_when_nobody_else_did(monkeypatch):
+    """`2dvof.py --gpus N` with no WORLD_SIZE / RANK around it hands the same argv to the launcher
+    (vof2d/launch.py: N fresh workers, this process never touches the GPU); under a launcher -- and
+    with one GPU -- it runs the rank itself."""
+    from vof2d import cli, launch
+    calls = []
+    monkeypatch.setattr(launch, "spawn_ranks", lambda script, argv, n, **kw: calls.append(("spawn", script, list(argv), n)) or 0)
+    monkeypatch.setattr(cli, "run", lambda args, **kw: calls.append(("run", args.gpus)) or 0)
+    for k in ("WORLD_SIZE", "RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert cli.main("/x/2dvof.py", ["-ic", "2", "--gpus", "4", "--steps", "10"]) == 0
+    assert calls == [("spawn", "/x/2dvof.py", ["-ic", "2", "--gpus", "4", "--steps", "10"], 4)]
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "2")
+    cli.main("/x/2dvof.py", ["--gpus", "4"])
+    cli.main("/x/2dvof.py", [])
+    assert calls[1:] == [("run", 4), ("run", 1)]
+    with pytest.raises(SystemExit):
+        cli.main("/x/2dvof.py", ["--gpus", "0"])
