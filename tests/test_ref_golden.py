@@ -91,8 +91,8 @@ def test_reference_vectors_present():
     shas = {str(Ref(n).z["ref_sha256"]) for n in REF_CASES if "ref_sha256" in Ref(n).z.files}
     assert len(shas) == 1 and len(shas.pop()) == 64       # the newer files say which 2dvof.py they came from
     f32_cases = [n for n in REF_CASES if Ref(n).dtype == "f32"]
-    assert {"ref_ic2_48x80_f32", "ref_ic3_40x56_f32_vis"} <= set(f32_cases)      # rectangular cells; the display path
-    for name in SHIPPED + tuple(n for n in SHIPPED_F32 if n in REF_CASES):
+    assert set(SHIPPED_F32) | {"ref_ic2_48x80_f32", "ref_ic3_40x56_f32_vis"} <= set(f32_cases)   # as shipped; rectangular cells; the display path
+    for name in SHIPPED + SHIPPED_F32:
         ref = Ref(name)
         assert ref.dtype == ("f32" if name in SHIPPED_F32 else "f64") and ref.z["F_1000"].dtype == (np.float32 if name in SHIPPED_F32 else np.float64)
         assert (ref.nx, ref.ny) == (200, 200) and ref.nsteps == 1000      # the shipped size; odd and even istep
