@@ -156,6 +156,13 @@ struct vof2d_ctx {
   void* f_home = nullptr;  // the buffer fld[fF] pointed to at creation (orientation of the F / twin pair)
   int phase_graph_ori = 0; // orientation the gphase / gxchg graphs were captured in
   hipGraphExec_t gexec[2][2] = {};  // whole step, [istep parity][F in its home buffer ? 0 : 1]
+  // several consecutive steady-state steps of a full domain as ONE graph (kStepBatch[b] steps, an even number: the
+  // F / twin pair and the step parity are back where they started): a graph launch leaves ~9 us of idle queue
+  // behind it, which one launch per step pays every step (vof_step)
+  static constexpr int kStepBatches = 2;
+  static constexpr int kStepBatch[kStepBatches] = {8, 2};   // (32 measured no better than 8)
+  hipGraphExec_t gbatch[kStepBatches][2][2] = {};   // [batch size][parity of the first step][orientation]
+  bool batches_built = false;   // the batch graphs of both reachable (parity, orientation) pairs are captured together
   hipGraphExec_t gphase[5] = {};  // phase 0, then phases 1, 2 x istep parity (slot 2 * phase - 1 + parity)
   int next_phase = 0;
   bool f_ghosts_dirty = true;  // F's ghost cells may not satisfy set_BC (after set_init_F / from_numpy / a single verb)

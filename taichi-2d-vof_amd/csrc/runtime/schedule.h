@@ -219,6 +219,11 @@ void destroy_graphs(vof2d_ctx* h) {
   for (int k = 0; k < 2; ++k)
     for (int o = 0; o < 2; ++o)
       if (h->gexec[k][o]) { (void)hipGraphExecDestroy(h->gexec[k][o]); h->gexec[k][o] = nullptr; }
+  for (int b = 0; b < vof2d_ctx::kStepBatches; ++b)
+    for (int k = 0; k < 2; ++k)
+      for (int o = 0; o < 2; ++o)
+        if (h->gbatch[b][k][o]) { (void)hipGraphExecDestroy(h->gbatch[b][k][o]); h->gbatch[b][k][o] = nullptr; }
+  h->batches_built = false;
   for (int k = 0; k < 5; ++k)
     if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }
 }

@@ -171,6 +171,7 @@ int vof_update_uv(vof2d_handle h) {
 // stale: drop the graphs (they are re-captured on the next vof_step / vof_step_phase).
 static void sweep_swapped(vof2d_handle h) {
   bool any = h->gexec[0][0] || h->gexec[0][1] || h->gexec[1][0] || h->gexec[1][1];
+  for (int k = 0; k < 4 * vof2d_ctx::kStepBatches; ++k) any = any || h->gbatch[k / 4][(k / 2) % 2][k % 2];
   for (int k = 0; k < 5; ++k) any = any || h->gphase[k];
   for (int k = 0; k < 20; ++k) any = any || h->gxchg[k / 10][(k / 2) % 5][k % 2];
   if (!any) return;
@@ -230,6 +231,50 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
     // a captured step holds the kernels of the handle's regular schedule; the one step after u / v
     // were written without a set_BC (stored ghost cells must be read as they are) runs eagerly
     const bool regular = !h->uv_ghosts_dirty;
+    if (use_graph && lean && regular && virt) {
+      // steady state of a full domain: as many of the remaining steps as possible in batches, one graph launch
+      // each.  An even number of steps leaves the F / twin pair and the host's view of it where they were.
+      // Parity and orientation flip together from step to step, so two (parity, orientation) pairs are
+      // reachable; the batch graphs of both are captured the first time a steady-state step comes by (captures
+      // enqueue nothing), so that no later call pays for an instantiation in the middle of a run.
+      if (!h->batches_built) {
+        for (int c = 0; c < 2; ++c) {
+          if (c) swap_F(h);                                   // the pair as the NEXT step will find it
+          const int64_t first = h->istep + c;
+          const int ori_c = h->fld[fF] == h->f_home ? 0 : 1;
+          for (int b = 0; b < vof2d_ctx::kStepBatches; ++b) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            for (int k = 0; k < vof2d_ctx::kStepBatch[b]; ++k)
+              DISPATCH_T(h, enqueue_step<double>(h, first + k, true, true), enqueue_step<float>(h, first + k, true, true));
+            HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
+            hipError_t e = hipGraphInstantiate(&h->gbatch[b][(int)(first & 1)][ori_c], graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) {
+              snprintf(h->err, sizeof(h->err), "hipGraphInstantiate: %s", hipGetErrorString(e));
+              if (c) swap_F(h);
+              return VOF_EHIP;
+            }
+          }
+          if (c) swap_F(h);
+        }
+        h->batches_built = true;
+      }
+      const int ori = h->fld[fF] == h->f_home ? 0 : 1;
+      bool batched = false;
+      for (int b = 0; b < vof2d_ctx::kStepBatches && !batched; ++b) {
+        const int K = vof2d_ctx::kStepBatch[b];
+        if (nsteps - s < K || !h->gbatch[b][par][ori]) continue;
+        HIPCHK(h, hipGraphLaunch(h->gbatch[b][par][ori], h->stream));
+        h->istep += K - 1;
+        s += K - 1;
+        batched = true;
+      }
+      if (batched) {
+        h->ghosts_virtual = true;
+        continue;
+      }
+    }
     if (use_graph && lean && regular) {
       // graphs bake the field pointers in: one per (parity, which buffer of the F / twin pair holds
       // F).  The two-kernel transport swaps the pair twice per step, the fused one once.

@@ -18,16 +18,15 @@ _api = None
 
 
 def kernel_source_hash():
-    """sha256 over the HIP sources of the product library (csrc/, csrc/kernels/, csrc/runtime/: *.h, *.hip).
-    Profiles that quote per-kernel hardware counters record it (profiles/jacobi_pmc.json), and
-    bench.py only repeats such a number while the sources it was measured on are the ones built."""
+    """sha256 over what decides a kernel's traffic per launch: the HIP kernels (csrc/vof2d_device.h,
+    vof2d_kernels.h, kernels/*.h) and the launch geometry (runtime/context.h: chunk-length heuristics,
+    runtime/launches.h: grids and arguments).  Profiles that quote per-kernel hardware counters record it
+    (profiles/jacobi_pmc.json), and bench.py only repeats such a number while it matches the built sources."""
     import hashlib
     src = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
     h = hashlib.sha256()
-    files = []
-    for sub in ("", "kernels", "runtime"):
-        d = os.path.join(src, sub)
-        files += [os.path.join(sub, n) for n in os.listdir(d) if n.endswith((".h", ".hip", ".inc"))]
+    files = ["vof2d_device.h", "vof2d_kernels.h", os.path.join("runtime", "context.h"), os.path.join("runtime", "launches.h")]
+    files += [os.path.join("kernels", n) for n in os.listdir(os.path.join(src, "kernels")) if n.endswith(".h")]
     for rel in sorted(files):
         h.update(rel.encode() + b"\0")
         with open(os.path.join(src, rel), "rb") as f:
