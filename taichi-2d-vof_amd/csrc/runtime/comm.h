@@ -91,6 +91,9 @@ void destroy_xchg_graphs(vof2d_ctx* h) {
     for (int b = 0; b < 5; ++b)
       for (int o = 0; o < 2; ++o)
         if (h->gxchg[a][b][o]) { (void)hipGraphExecDestroy(h->gxchg[a][b][o]); h->gxchg[a][b][o] = nullptr; }
+  for (int a = 0; a < 2; ++a)
+    for (int o = 0; o < 2; ++o)
+      if (h->gxchg2[a][o]) { (void)hipGraphExecDestroy(h->gxchg2[a][o]); h->gxchg2[a][o] = nullptr; }
 }
 int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1) {
   Rccl* r = rccl();

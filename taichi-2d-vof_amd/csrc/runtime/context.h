@@ -185,6 +185,8 @@ struct vof2d_ctx {
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr};  // one per exchange of a step (graph capture forks)
   hipGraphExec_t gxchg[2][5][2] = {};   // whole step + exchanges, [istep parity][overlap mode][F / twin orientation]
+  hipGraphExec_t gxchg2[2][2] = {};     // TWO mode-4 steps + exchanges per launch, [parity of the first][orientation] (vof_step_exchange)
+  int xchg_pair = 1;                 // 0 after a failed capture of a pair: one step per launch
   int xchg_graph = 1;                // 0 after a failed capture (or VOF2D_XCHG_GRAPH=0): eager launches
   int64_t xchg_steps = 0;            // steps run by vof_step_exchange (the first one is always eager)
   int64_t xchg_graph_steps = 0;      // ... of which replayed from a captured graph

@@ -839,6 +839,52 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
     // and three RCCL group launches (~100 us of host time each).
     const int ori = h->fld[fF] == h->f_home ? 0 : 1;
     const bool one_swap = overlap == 4;   // the fused transport swaps the F / twin pair once per step
+    // Two mode-4 steps per graph launch (a graph launch leaves ~9 us of idle queue behind it, see vof_step):
+    // only once both single-step graphs of this handle exist, i.e. this RCCL has shown that it can be
+    // captured; two steps return the F / twin pair and the parity to where they were.
+    if (captured_path && overlap == 4 && h->xchg_pair && virt && nsteps - s >= 2 && h->gxchg[par][4][ori] &&
+        h->gxchg[par ^ 1][4][ori ^ 1]) {
+      if (!h->gxchg2[par][ori]) {
+        void* keep[NFIELDS];
+        memcpy(keep, h->fld, sizeof(keep));
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed);
+        rc = VOF_OK;
+        if (e == hipSuccess) {
+          DISPATCH_T(h, rc = enqueue_step_exchange<double>(h, 4), rc = enqueue_step_exchange<float>(h, 4));
+          h->istep += 1;
+          if (rc == VOF_OK) DISPATCH_T(h, rc = enqueue_step_exchange<double>(h, 4), rc = enqueue_step_exchange<float>(h, 4));
+          h->istep -= 1;
+          e = hipStreamEndCapture(h->stream, &graph);
+        }
+        if (e == hipSuccess && rc == VOF_OK && graph) e = hipGraphInstantiate(&h->gxchg2[par][ori], graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        memcpy(h->fld, keep, sizeof(keep));
+        if (e != hipSuccess || rc != VOF_OK || !h->gxchg2[par][ori]) {
+          (void)hipGetLastError();
+          h->gxchg2[par][ori] = nullptr;
+          h->xchg_pair = 0;   // single-step graphs from here on (they are known to work)
+          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(h->cstream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            (void)hipStreamDestroy(h->cstream);
+            h->cstream = nullptr;
+            if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess)
+              return fail(h, VOF_EHIP, "cannot recreate the communication stream after a failed capture");
+          }
+          if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] two-step exchange graph capture failed (%s): one step per launch\n", hipGetErrorString(e));
+        }
+      }
+      if (h->gxchg2[par][ori]) {
+        HIPCHK(h, hipGraphLaunch(h->gxchg2[par][ori], h->stream));
+        h->istep += 1;
+        s += 1;
+        h->xchg_steps += 2;
+        h->xchg_graph_steps += 2;
+        h->ghosts_virtual = virt;
+        continue;
+      }
+    }
     if (captured_path) {
       if (!h->gxchg[par][overlap][ori]) {
         void* keep[NFIELDS];
