@@ -106,7 +106,8 @@ int vof_post_process_f(vof2d_handle h);             /* :452-455 */
  * kernel schedule: on a full domain four launches per step -- k_momentum, two
  * five-sweep k_jacobi_tb, k_transport -- replayed from a hipGraph (the first step after set_init_F /
  * set_field / a single verb runs eagerly with the intermediate boundary launches the reference's
- * :518 / :525 stand for).  rho/nu/kappa scratch is not materialised. */
+ * :518 / :525 stand for; steady-state steps are replayed in batches of eight, then two, per graph launch).
+ * rho/nu/kappa scratch is not materialised. */
 int vof_step(vof2d_handle h, int64_t nsteps);
 /* The same step split at the points where a field becomes final, for drivers that overlap the
  * halo exchange with compute (vof2d/strips.py, vof_step_exchange):
@@ -220,7 +221,8 @@ int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep);
  *                           (k_transport), first on the edge bands, then
  *                           send/recv p, u, v, F in one group, and the same kernel on the remaining
  *                           rows while they travel.  After the first step (RCCL connects on
- *                           first use) a step and its exchanges are one hipGraph launch; if the
+ *                           first use) a step and its exchanges are one hipGraph launch (mode 4: two
+ *                           steps per launch once both single-step graphs exist); if the
  *                           RCCL at hand cannot be captured the launches stay eager.  The host
  *                           does not block
  *   vof_comm_exchange       one exchange of the fields in field_mask, then join (for verb-level
