@@ -1,4 +1,4 @@
-// runtime/launches.h -- L<T>: one launch wrapper per kernel (grid shape, chunk length, arguments), through the single launch() helper
+// runtime/launches.h -- chunk-length heuristics and L<T>: one launch wrapper per kernel (grid shape, chunk length, arguments), through the single launch() helper
 //
 // Part of the host-side runtime of libvof2d_hip.so; included (once, in this order) by vof2d_api.hip:
 // context.h, launches.h, schedule.h, comm.h, selftest.h.  Everything here has internal linkage.
@@ -6,6 +6,89 @@
 #include "context.h"
 
 namespace {
+
+// ------------------------------------------------------------------ chunk lengths (launch geometry)
+// Rows per wave chunk.  Every marching kernel trades lead-in / halo rows per chunk (re-read from
+// HBM by the vertical neighbour) against the number of waves.  Two effects decide:
+//  * residency rounds: a launch whose waves exceed what the chip holds at once (occupancy x 1024
+//    SIMDs) by a little runs a nearly empty extra round (measured on k_jacobi_tb at 4096^2: 3010
+//    waves 116 us, 3080 waves 158 us), so the chunk length is chosen to make the launch k full
+//    rounds, k as small as the maximum chunk length allows;
+//  * with few cells the critical path of one wave dominates, so chunks never exceed what keeps
+//    one round's worth of waves busy (short chunks on small grids).
+// Occupancy comes from the runtime's query for the actual kernel (it depends on the compiled
+// register count); a 5 % margin absorbs the over-reporting noted in MI355X_MICROARCH.md.
+// Used for the two register-heavy, long-lived-wave kernels (k_jacobi_tb: -15 us per step at
+// 4096^2, k_momentum: -3 us); the HBM-bound kernels with short-lived waves measured best with the
+// plain cells-per-wave rule (chunk_rows) and keep it.
+template <typename K>
+long resident_waves(vof2d_ctx* h, K kernel) {
+  std::map<const void*, long>& cache = h->occ_cache;  // per handle (one host thread per handle)
+  const void* key = reinterpret_cast<const void*>(kernel);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int blocks_per_cu = 0;
+  long cap = 3L * 256 * 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) == hipSuccess && blocks_per_cu > 0) {
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    if (blocks_per_cu > 8) blocks_per_cu = 8;  // 32 waves per CU
+    cap = (long)blocks_per_cu * cus * 4;
+  } else {
+    (void)hipGetLastError();
+  }
+  cache[key] = cap;
+  return cap;
+}
+int chunk_rows_fit(const vof2d_ctx* h, int ntiles, long capacity, int rmin, int rmax) {
+  const long rows = h->g.ihi - h->g.ilo + 1;
+  const long cap = capacity * 95 / 100;
+  int R_out = rmin;
+  for (int k = 1; k <= 64; ++k) {
+    long chunks_max = k * cap / ntiles;
+    if (chunks_max < 1) continue;
+    long R = (rows + chunks_max - 1) / chunks_max;
+    if (R <= rmax) { R_out = (int)(R < rmin ? rmin : R); break; }
+  }
+  if (getenv("VOF2D_DEBUG"))
+    fprintf(stderr, "[vof2d] chunk_rows_fit: rows=%ld tiles=%d capacity=%ld -> R=%d (%ld waves)\n", rows, ntiles,
+            capacity, R_out, ((rows + R_out - 1) / R_out) * ntiles);
+  return R_out;
+}
+// cells-per-wave rule (~4096 waves, chunk length a power of two), used by the x sweep, whose 6
+// lead-in rows per chunk want long chunks (16 rows at 4096^2: 143 us; 8 rows 157 us, 4 rows 200 us)
+int chunk_rows(const vof2d_ctx* h, int ntiles, int rmin, int rmax) {
+  const long rows = h->g.ihi - h->g.ilo + 1;
+  long R = rows * ntiles / 4096;
+  if (R < rmin) R = rmin;
+  if (R > rmax) R = rmax;
+  long P = 1;
+  while (P * 2 <= R) P *= 2;
+  return (int)(P < rmin ? rmin : P);
+}
+// The streaming kernels with at most one halo row per side (single-sweep Jacobi, y sweep, the
+// per-verb kernels): very short chunks.  With the nontemporal hints on their single-use streams the
+// halo rows of vertically adjacent chunks -- consecutive blocks, resident at the same time -- are
+// L2 hits, and many short-lived waves balance better than few long ones: k_jacobi at 4096^2 fp64
+// 64 us with 2-row chunks (1 row 72 us, 4 rows 65 us, 8 rows 69 us, 32 rows 73.5 us); y sweep 112 us
+// with 1 row, 116 us with 2, 136 us with 16.
+int pick_rows(const vof2d_ctx* h, int ntiles) {
+  (void)ntiles;
+  if (h->rows_override > 0) return h->rows_override;
+  return 2;
+}
+inline unsigned blocks_rows(int rows, int ntiles, int R) {
+  const long waves = (long)((rows + R - 1) / R) * ntiles;
+  return (unsigned)((waves + 3) / 4);
+}
+inline unsigned blocks_for(const vof2d_ctx* h, int ntiles, int R) {
+  const int rows = h->g.ihi - h->g.ilo + 1;
+  const long chunks = (rows + R - 1) / R;
+  const long waves = chunks * ntiles;
+  return (unsigned)((waves + 3) / 4);
+}
 
 // ------------------------------------------------------------------ launches
 constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe

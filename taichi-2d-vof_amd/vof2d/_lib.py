@@ -19,13 +19,13 @@ _api = None
 
 def kernel_source_hash():
     """sha256 over what decides a kernel's traffic per launch: the HIP kernels (csrc/vof2d_device.h,
-    vof2d_kernels.h, kernels/*.h) and the launch geometry (runtime/context.h: chunk-length heuristics,
-    runtime/launches.h: grids and arguments).  Profiles that quote per-kernel hardware counters record it
+    vof2d_kernels.h, kernels/*.h) and the launch geometry (runtime/launches.h: chunk-length heuristics, grids
+    and arguments).  Profiles that quote per-kernel hardware counters record it
     (profiles/jacobi_pmc.json), and bench.py only repeats such a number while it matches the built sources."""
     import hashlib
     src = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
     h = hashlib.sha256()
-    files = ["vof2d_device.h", "vof2d_kernels.h", os.path.join("runtime", "context.h"), os.path.join("runtime", "launches.h")]
+    files = ["vof2d_device.h", "vof2d_kernels.h", os.path.join("runtime", "launches.h")]
     files += [os.path.join("kernels", n) for n in os.listdir(os.path.join(src, "kernels")) if n.endswith(".h")]
     for rel in sorted(files):
         h.update(rel.encode() + b"\0")
