@@ -440,7 +440,12 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
   WaveTimer wt_(WT_TRANSPORT);
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+#ifdef VOF_VSTACK
+  const int tj = (int)blockIdx.x % nty, ch = 4 * ((int)blockIdx.x / nty) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  (void)wave;
+#else
   const int tj = wave % nty, ch = wave / nty;
+#endif
   const int c0 = -3 + tj * STRIDE;
   const int j0 = c0 + lane * V;
   const int ilo = g.ilo, ihi = g.ihi, nx = g.nx, ny = g.ny;

@@ -171,7 +171,12 @@ struct L {
     int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, resident_waves(h, k_momentum<T, V>), 4, 64);
     if (h->mom_rows <= 0 && R > 32) R = 14;
     const TbPlan tp = tb_plan(h, adapt_par);   // (one extra block: the planner wave)
-    launch(h, kMomentum, k_momentum<T, V>, dim3(blocks_for(h, ntt, R) + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+#ifdef VOF_VSTACK
+    const unsigned mom_blocks = (unsigned)ntt * (unsigned)(((h->g.ihi - h->g.ilo + R) / R + 3) / 4);
+#else
+    const unsigned mom_blocks = blocks_for(h, ntt, R);
+#endif
+    launch(h, kMomentum, k_momentum<T, V>, dim3(mom_blocks + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
            (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
            virt ? 1 : 0, tp);
   }
@@ -297,7 +302,12 @@ struct L {
     RowRanges rr;
     if (ranges) rr = *ranges;
     else rr = RowRanges{{h->g.ilo, 1, 1}, {h->g.ihi, 0, 0}, {transport_rows(h), 1, 1}};
-    launch(h, kTransport, k_transport<T, V, YFIRST>, dim3((unsigned)((range_chunks(rr) * h->nty + 3) / 4)), 0, h->g, C(h),
+#ifdef VOF_VSTACK
+    const unsigned tr_blocks = (unsigned)(((range_chunks(rr) + 3) / 4) * h->nty);
+#else
+    const unsigned tr_blocks = (unsigned)((range_chunks(rr) * h->nty + 3) / 4);
+#endif
+    launch(h, kTransport, k_transport<T, V, YFIRST>, dim3(tr_blocks), 0, h->g, C(h),
            (const T*)F_<T>(h, fF), F_<T>(h, fF2), h->nty, (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS),
            (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, rr);
   }
