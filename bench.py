@@ -38,8 +38,11 @@ KERNEL_PASSES = {"k_momentum": 6, "k_jacobi_tb": 3, "k_transport": 7, "k_jacobi"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: 0.12 s at 4096^2)")
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed steps before them.  The first step after set_init_F runs the eager two-kernel schedule; "
+                         "the library uploads its step graphs when it builds them, so no first-launch cost falls into "
+                         "the timed region whatever W is")
     ap.add_argument("--nx", type=int, default=0, help="grid size (default 4096 at 1 GPU, 8192 at N > 1)")
     ap.add_argument("--ny", type=int, default=0)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -54,6 +57,9 @@ def parse():
                     help="N = 1: skip the sustained 1000-step record and the 1024^2 residual-terminated solve "
                          "(the rocprofv3 profiles: one workload per trace)")
     ap.add_argument("--sustained-steps", type=int, default=1000)
+    ap.add_argument("--profile-steps", type=int, default=350,
+                    help="N = 1: steps of the in-situ kernel profile behind `roofline` and `step_kernels` (a fresh run, steps "
+                         "11 .. 10 + this many: with the default it covers the start of the tiny-value front, steps ~65-600)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed/StripSolver code path even with one rank (self-test)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline's main sample")
@@ -409,6 +415,25 @@ def run_fast_leg(a):
     return json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
 
 
+def roofline_record(step_kernels, traffic, traffic_note, nprof, prof_note, sweep_bytes, fused, tb, single):
+    """The `roofline` object of the line: k_jacobi_tb from the in-situ profile; if the profile is missing (N > 1, or the
+    second engine did not fit) the back-to-back figure of vof_time_jacobi stands in and says so."""
+    k = step_kernels.get("k_jacobi_tb")
+    if k:
+        us, src = k["us_per_launch_dispatch"], "in-situ profile, %d steps from step 11 of a fresh run" % nprof
+    else:
+        us, src = fused["us_per_launch_back_to_back"], "back-to-back launches (vof_time_jacobi): %s" % (prof_note or "no in-situ profile on this path")
+    achieved = sweep_bytes / (us * 1e-6) / 1e9
+    low = None
+    if step_kernels:
+        n = min(step_kernels, key=lambda x: step_kernels[x]["frac_of_peak"])
+        low = dict(step_kernels[n], kernel=n, peak=HBM_PEAK_GBS, unit="GB/s", achieved=step_kernels[n]["frac_of_peak"] * HBM_PEAK_GBS)
+    return {"bound": "hbm", "kernel": "k_jacobi_tb", "sweeps_per_launch": tb, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("tb"), "traffic_note": traffic_note,
+            "us_per_launch": us, "algorithmic_bytes_per_launch": sweep_bytes, "duration_source": src,
+            "in_step_lowest": low, "north_star_single_sweep": single}
+
+
 # --------------------------------------------------------------------------------------------------
 def main():
     a = parse()
@@ -628,20 +653,26 @@ def main():
                 speedup = (nx * ny * a.steps / elapsed) / ref8192["value"]
         except Exception as exc:   # e.g. not enough free HBM
             ref8192 = {"error": str(exc)}
-    # the kernels of the step under the built-in profiler, on a fresh run of the same workload (steps 11-24):
-    # `eng` has just had its p advanced by the back-to-back Jacobi launches above, which is not a state the
-    # solver passes through (and puts tiny values under the first launches)
-    prof = {}
+    # the kernels of the step under the built-in profiler (one HIP event pair per dispatch, on the stream the kernels are
+    # launched on), on a fresh run of the same workload, steps 11 .. 10 + --profile-steps: long enough to contain the
+    # regime in which the tiny-value front of the pressure iteration crosses the grid.  (`eng` has just had its p
+    # advanced by the back-to-back Jacobi launches above, which is not a state the solver passes through.)
+    prof, prof_note, nprof = {}, None, max(1, a.profile_steps)
     if not dist_path:
-        from vof2d.engine import Engine as _E, make_desc as _md
-        e1 = _E(api, _md(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters, dt=dt))
-        e1.set_init_F(a.ic)
-        e1.step(10)
-        prof = e1.profile_steps(14)
-        e1.close()
+        try:
+            from vof2d.engine import Engine as _E, make_desc as _md
+            e1 = _E(api, _md(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters, dt=dt))
+            try:
+                e1.set_init_F(a.ic)
+                e1.step(10)
+                prof = e1.profile_steps(nprof)
+            finally:
+                e1.close()
+        except Exception as exc:      # e.g. not enough free HBM for a second engine: the line survives without the breakdown
+            prof, prof_note = {}, "in-situ profile failed: %s" % (exc,)
     kernels_us = {k: round(v[0], 2) for k, v in prof.items()}
     cells = nx * ny
-    step_kernels = {k: {"launches_per_step": round(v[1] / 14.0, 2), "algorithmic_passes": KERNEL_PASSES[k],
+    step_kernels = {k: {"launches_per_step": round(v[1] / float(nprof), 2), "algorithmic_passes": KERNEL_PASSES[k],
                         "algorithmic_bytes_per_launch": KERNEL_PASSES[k] * esz * cells, "us_per_launch_dispatch": round(v[0], 2),
                         "frac_of_peak": KERNEL_PASSES[k] * esz * cells / (v[0] * 1e-6) / 1e9 / HBM_PEAK_GBS}
                     for k, v in prof.items() if k in KERNEL_PASSES and v[0] > 0}
@@ -687,19 +718,18 @@ def main():
                 "multi_gpu_hardware_verified": False if world > 1 else None,
                 "arrays_per_cell_update": ARRAYS_PER_STEP,
                 "bytes_per_cell_update_algorithmic": ARRAYS_PER_STEP * esz},
-            # The Poisson Jacobi kernel (north star): algorithmic bytes = 3 arrays x sizeof(T) x
-            # cells per launch, duration from the HIP-event pair above; `traffic` = HBM
-            # bytes per launch from the committed rocprofv3 --pmc passes (profiles/jacobi_pmc.json).
-            "roofline": {"bound": "hbm", "kernel": "k_jacobi", "achieved": achieved_1, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved_1 / HBM_PEAK_GBS, "traffic": traffic.get("single"),
-                         "traffic_note": traffic_note,
-                         "us_per_launch": 1e3 * ms_sweep_1, "algorithmic_bytes_per_launch": sweep_bytes,
-                         "launches_timed": max(2, a.jacobi_sweeps_timed // 2 * 2),
-                         # k_jacobi is the north star's "Poisson Jacobi kernel" (one sweep, 24 B per cell), but the
-                         # step runs its sweeps fused: the lowest-fraction kernel of the step itself, same rule
-                         "in_step_lowest": (lambda k: dict(step_kernels[k], kernel=k, peak=HBM_PEAK_GBS, unit="GB/s",
-                                                           achieved=step_kernels[k]["frac_of_peak"] * HBM_PEAK_GBS))(
-                             min(step_kernels, key=lambda n: step_kernels[n]["frac_of_peak"])) if step_kernels else None},
+            # `roofline` = the Poisson Jacobi kernel THE STEP RUNS, k_jacobi_tb (five sweeps per launch): algorithmic bytes =
+            # 3 arrays x sizeof(T) x cells per launch (read p, read rhs, write p after five sweeps; SURVEY 8d's 24 B rule
+            # per launch), duration = its average dispatch over the in-situ profile above (HIP events on the launch
+            # stream, steps 11 .. 10 + --profile-steps of a fresh run, the tiny-value front included); `traffic` = HBM
+            # bytes per launch from the committed rocprofv3 --pmc passes (profiles/jacobi_pmc.json).  The single-sweep
+            # kernel of the north star's wording (k_jacobi, not launched by the step) is `north_star_single_sweep`.
+            "roofline": roofline_record(step_kernels, traffic, traffic_note, nprof, prof_note, sweep_bytes, fused, tb, {
+                "kernel": "k_jacobi", "bound": "hbm", "achieved": achieved_1, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_1 / HBM_PEAK_GBS, "traffic": traffic.get("single"), "us_per_launch": 1e3 * ms_sweep_1,
+                "algorithmic_bytes_per_launch": sweep_bytes, "launches_timed": max(2, a.jacobi_sweeps_timed // 2 * 2),
+                "note": "one sweep per launch, back-to-back launches between one HIP event pair (vof_time_jacobi); used by "
+                        "the step only for sweep counts that are not a multiple of five and for the residual checks"}),
             "jacobi_fused": fused,
             # the kernels the step itself runs, same counting rule (built-in profiler: dispatch start ->
             # stop; reads a few us high behind a long-tailed predecessor -- rocprofv3, profiles/, is the reference)

@@ -100,18 +100,13 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   // set_BC; the ghost cells this kernel reads -- F's ghost rows and columns, v's ghost rows, u's
   // ghost columns -- are formed from the interior cells set_BC would have copied (:164-189).
   constexpr int W = 64 * V;
-  constexpr int H = ((2 + V - 1) / V) * V;
+  constexpr int H = TileHalo::momentum;
+  static_assert(H >= 2 && H % V == 0, "two columns of each side are invalid after the cross-lane stages");
   WaveTimer wt_(WT_MOMENTUM);
   constexpr int STRIDE = W - 2 * H;
   const int wave = ((int)blockIdx.x - plan_blocks) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-#ifdef VOF_VSTACK
-  const int vb_ = (int)blockIdx.x - plan_blocks;
-  const int tj = vb_ % ntt, ch = 4 * (vb_ / ntt) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  (void)wave;
-#else
   const int tj = wave % ntt, ch = wave / ntt;
-#endif
   const int c0 = 1 - H + tj * STRIDE;
   const int j0 = c0 + lane * V;
   const int ra = g.ilo + ch * R;

@@ -57,6 +57,14 @@ __device__ __forceinline__ T fct_final(const Consts<T>& c, T ftd, T alo, T clo, 
   return f;
 }
 
+// stage D where both anti-diffusive fluxes of the cell are exact zeros: F = var(0, 1, F~ - 0)
+template <typename T, bool POST>
+__device__ __forceinline__ T fct_clamp(T ftd) {
+  T f = var3((T)0, (T)1, ftd);
+  if (POST) f = var3(f, (T)0, (T)1);
+  return f;
+}
+
 // 2dvof.py:321-382 fct_x_sweep, the four barrier-separated loops fused into
 // one pass: each lane marches along i (the sweep direction) with a 3-row-deep
 // software pipeline (face -> Ftd -> rp/rm -> cx -> F').  Out of place: reads
@@ -88,6 +96,18 @@ __device__ __forceinline__ void fct_y_row(const Consts<T>& c, int j0, int ny, co
     const int j = j0 + q;
     dv[q] = c.dxdy - c.dtdx * ((q == V - 1 ? vn : vz[q + 1]) - vz[q]);
     td[q] = (j >= 1 && j <= ny) ? fct_ftd<T>(c, Fz[q], L[q], q == V - 1 ? Ln : L[q + 1], dv[q]) : (T)0;
+  }
+  // Stages B, C, D.  Where every anti-diffusive flux the wave holds is an exact zero (F uniform along the sweep:
+  // the bulk of either phase) the limiter ratios of :417-429 are 0 (pp = pm = 0), so are the face limiters, and stage
+  // D subtracts (0 / dy) * dx * dy / dv = 0: the new F is the clamped F~.  One wave-level test replaces two IEEE
+  // divisions, the limiter and the division by dv per cell.
+  bool anz = an_ != (T)0;
+#pragma unroll
+  for (int q = 0; q < V; ++q) anz = anz || a[q] != (T)0;
+  if (!__any(anz)) {
+#pragma unroll
+    for (int q = 0; q < V; ++q) out[q] = fct_clamp<T, POST>(td[q]);
+    return;
   }
   const T tl = lane_up(td[V - 1]), tr = lane_dn(td[0]);
   T rp[V], rm[V];
@@ -121,6 +141,10 @@ template <typename T, int V>
 struct FctXPipe {
   T F1[V], u1[V], L1[V], a1[V], a2[V], a3[V], t2[V], t3[V], d2[V], d3[V], rp3[V], rm3[V], c3[V];
   int zrows;
+  // wave-uniform flags: some lane of the wave holds a non-zero anti-diffusive flux on the face row (nz1 / nz2 / nz3
+  // for a1 / a2 / a3), a non-zero limiter ratio in the cell row behind (nzr3 for rp3, rm3).  Where a flag is false
+  // the stage that would multiply or divide by those zeros is skipped: its results are the same exact zeros.
+  bool nz1, nz2, nz3, nzr3;
   __device__ __forceinline__ void init(const T (&Fm)[V]) {  // Fm = F[row before the first pushed row]
 #pragma unroll
     for (int q = 0; q < V; ++q) {
@@ -129,14 +153,13 @@ struct FctXPipe {
       d2[q] = d3[q] = (T)1;
     }
     zrows = 0;
+    nz1 = nz2 = nz3 = nzr3 = false;
   }
+  // zero_row: Fr is an exact zero on every lane of the wave (the caller has looked at the row anyway)
   template <bool POST>
   __device__ __forceinline__ void push(const Consts<T>& c, int r, int ilo, int ihi, const T (&Fr)[V],
-                                       const T (&ur)[V], T (&out)[V]) {
-    bool rz = true;
-#pragma unroll
-    for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
-    zrows = __all(rz) ? zrows + 1 : 0;
+                                       const T (&ur)[V], T (&out)[V], bool zero_row) {
+    zrows = zero_row ? zrows + 1 : 0;
     if (zrows >= 7) {  // the whole dependency window F[r-6..r] of the wave is zero: every output is
 #pragma unroll
       for (int q = 0; q < V; ++q) {
@@ -148,26 +171,59 @@ struct FctXPipe {
         d3[q] = d2[q]; d2[q] = dv1;
         rp3[q] = rm3[q] = c3[q] = (T)0;
       }
+      nz1 = nz2 = nz3 = nzr3 = false;
+      return;
+    }
+    const int i1 = r - 1, i2 = r - 2;
+    const bool in1 = i1 >= ilo && i1 <= ihi, in2 = i2 >= ilo && i2 <= ihi, inc2 = i2 > ilo && i2 <= ihi + 1;   // wave-uniform
+    T Lr[V], ar[V], dv1[V], tn[V];
+    bool nzr = false;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      fct_face<T>(ur[q], c.dt, F1[q], Fr[q], Lr[q], ar[q]);
+      nzr = nzr || ar[q] != (T)0;
+      dv1[q] = c.dxdy - c.dtdy * (ur[q] - u1[q]);
+      tn[q] = (T)0;
+    }
+    const bool nz0 = __any(nzr);
+    if (in1) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) tn[q] = fct_ftd<T>(c, F1[q], L1[q], Lr[q], dv1[q]);
+    }
+    // stage B of row r-2 (faces a2 below, a1 above): all fluxes zero -> pp = pm = 0 -> both ratios 0
+    T rp2[V], rm2[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) rp2[q] = rm2[q] = (T)0;
+    const bool nzr2 = in2 && (nz2 || nz1);
+    if (nzr2) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) fct_ratios<T>(c, t2[q], t3[q], tn[q], a2[q], a1[q], rp2[q], rm2[q]);
+    }
+    // stage C of face r-2: a minimum of two ratios, all of them zero unless one of the two cell rows has some
+    T c2[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) c2[q] = (T)0;
+    if (inc2 && (nzr2 || nzr3)) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) c2[q] = fct_climit<T>(a2[q], rp3[q], rm3[q], rp2[q], rm2[q]);
+    }
+    // stage D of row r-3 (faces a3 below, a2 above)
+    if (nz3 || nz2) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) out[q] = fct_final<T, POST>(c, t3[q], a3[q], c3[q], a2[q], c2[q], d3[q]);
     } else {
 #pragma unroll
-      for (int q = 0; q < V; ++q) {
-        T Lr, ar;
-        fct_face<T>(ur[q], c.dt, F1[q], Fr[q], Lr, ar);
-        const int i1 = r - 1;
-        T dv1 = c.dxdy - c.dtdy * (ur[q] - u1[q]);
-        T tn = (i1 >= ilo && i1 <= ihi) ? fct_ftd<T>(c, F1[q], L1[q], Lr, dv1) : (T)0;
-        const int i2 = r - 2;
-        T rp2 = (T)0, rm2 = (T)0;
-        if (i2 >= ilo && i2 <= ihi) fct_ratios<T>(c, t2[q], t3[q], tn, a2[q], a1[q], rp2, rm2);
-        T c2 = (i2 > ilo && i2 <= ihi + 1) ? fct_climit<T>(a2[q], rp3[q], rm3[q], rp2, rm2) : (T)0;
-        out[q] = fct_final<T, POST>(c, t3[q], a3[q], c3[q], a2[q], c2, d3[q]);
-        F1[q] = Fr[q]; u1[q] = ur[q]; L1[q] = Lr;
-        a3[q] = a2[q]; a2[q] = a1[q]; a1[q] = ar;
-        t3[q] = t2[q]; t2[q] = tn;
-        d3[q] = d2[q]; d2[q] = dv1;
-        rp3[q] = rp2; rm3[q] = rm2; c3[q] = c2;
-      }
+      for (int q = 0; q < V; ++q) out[q] = fct_clamp<T, POST>(t3[q]);
     }
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      F1[q] = Fr[q]; u1[q] = ur[q]; L1[q] = Lr[q];
+      a3[q] = a2[q]; a2[q] = a1[q]; a1[q] = ar[q];
+      t3[q] = t2[q]; t2[q] = tn[q];
+      d3[q] = d2[q]; d2[q] = dv1[q];
+      rp3[q] = rp2[q]; rm3[q] = rm2[q]; c3[q] = c2[q];
+    }
+    nz3 = nz2; nz2 = nz1; nz1 = nz0; nzr3 = nzr2;
   }
 };
 
@@ -280,7 +336,10 @@ __global__ __launch_bounds__(256) void k_fct_x(Geom g, Consts<T> c, const T* __r
     // F are exact zeros: the pipeline bypasses itself once the wave's whole 7-row dependency window
     // is zero (FctXPipe::push).
     T out[V];
-    pipe.template push<POST>(c, r, ilo, ihi, Fr, ur, out);
+    bool rz = true;
+#pragma unroll
+    for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
+    pipe.template push<POST>(c, r, ilo, ihi, Fr, ur, out, __all(rz));
     const int io = r - 3;
     if (io >= ra && io <= rb) store_s<T, V>(Fn + at(g, io, j0), out, j0, 1, g.ny);
   }
@@ -302,19 +361,20 @@ __global__ __launch_bounds__(256) void k_fct_y(Geom g, Consts<T> c, const T* __r
                                                 const T* __restrict__ us, const T* __restrict__ vs,
                                                 const T* __restrict__ p, T* __restrict__ Uo, T* __restrict__ Vo,
                                                 unsigned long long* __restrict__ courant, int rfirst, int rlast) {
-  constexpr int W = 64 * V, STRIDE = W - 8;
+  constexpr int W = 64 * V, HT = TileHalo::transport, STRIDE = W - 2 * HT;
+  static_assert(HT >= 4 && HT % V == 0, "the y sweep's +-3 dependency is resolved across lanes");
   WaveTimer wt_(WT_FCT_Y);
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR: rows are wave-uniform
   const int lane = threadIdx.x & 63;
   const int tj = wave % nty, ch = wave / nty;
-  const int c0 = -3 + tj * STRIDE;
+  const int c0 = 1 - HT + tj * STRIDE;
   const int j0 = c0 + lane * V;
   const int ra = rfirst + ch * R;
   if (ra > rlast) return;  // wave-uniform
   const int rb = ra + R - 1 < rlast ? ra + R - 1 : rlast;
   const int ny = g.ny;
-  const int jlo = c0 + 4 > 1 ? c0 + 4 : 1;
-  const int jhi = c0 + W - 5 < ny ? c0 + W - 5 : ny;
+  const int jlo = c0 + HT > 1 ? c0 + HT : 1;
+  const int jhi = c0 + W - HT - 1 < ny ? c0 + W - HT - 1 : ny;
   size_t o = at(g, ra, j0);
   T Fnx[V], vnx[V];  // next row (CORR: v*), prefetched
   load_c<T, V>(Fnx, F + o);
@@ -436,17 +496,13 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
   // rr: all computable rows of a full domain; on a strip the owned rows -- as one range, or the two
   // edge bands (what the neighbours wait for) first and then the rest, in one launch or in two.
   // The sweeps' domain stays [ilo, ihi].
-  constexpr int W = 64 * V, STRIDE = W - 8;
+  constexpr int W = 64 * V, HT = TileHalo::transport, STRIDE = W - 2 * HT;
+  static_assert(HT >= 4 && HT % V == 0, "the y sweep's +-3 dependency is resolved across lanes");
   WaveTimer wt_(WT_TRANSPORT);
   const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-#ifdef VOF_VSTACK
-  const int tj = (int)blockIdx.x % nty, ch = 4 * ((int)blockIdx.x / nty) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  (void)wave;
-#else
   const int tj = wave % nty, ch = wave / nty;
-#endif
-  const int c0 = -3 + tj * STRIDE;
+  const int c0 = 1 - HT + tj * STRIDE;
   const int j0 = c0 + lane * V;
   const int ilo = g.ilo, ihi = g.ihi, nx = g.nx, ny = g.ny;
   int k = 0, cbase = 0;   // range of this chunk (wave-uniform)
@@ -459,8 +515,8 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
   const int R = rr.R[k], hi = rr.last[k];
   const int ra = rr.first[k] + (ch - cbase) * R;
   const int rb = ra + R - 1 < hi ? ra + R - 1 : hi;
-  const int jlo = c0 + 4 > 1 ? c0 + 4 : 1;
-  const int jhi = c0 + W - 5 < ny ? c0 + W - 5 : ny;
+  const int jlo = c0 + HT > 1 ? c0 + HT : 1;
+  const int jhi = c0 + W - HT - 1 < ny ? c0 + W - HT - 1 : ny;
   auto rowptr = [&](const T* base, int r) {
     const int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
     return base + at(g, rc, j0);
@@ -492,6 +548,7 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
       pipe.init(f1);
     }
   }
+  int cls1 = 2;           // class of the previous row (see the loop); 2: rho1 holds the row's densities lane by lane
   T v1[V], v2[V], v3[V];  // x first: corrected v of rows r-1, r-2, r-3 (the y sweep trails the pipeline)
 #pragma unroll
   for (int q = 0; q < V; ++q) v1[q] = v2[q] = v3[q] = (T)0;
@@ -520,27 +577,68 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
       if (YFIRST || (r + 1 >= ra && r + 1 <= rb)) load_s<T, V>(vsnx, rowptr(vs, r + 1));
       load_c<T, V>(pnx, rowptr(p, r + 1));
     }
-    {  // update_uv for row r (:269-280): ur / vr hold u*[r] / v*[r]
-      T rhor[V];
+    // Class of the row as the wave sees it (wave-uniform): 0 = F is an exact 0 on every lane (gas), 1 = an exact 1
+    // (liquid), 2 = anything else.  In a class-0 / class-1 row rho is rho_g / rho_l on every lane (rho_of(0) =
+    // rho_g * 1 + rho_l * 0, rho_of(1) = rho_g * 0 + rho_l * 1: exact), and when the row below has the same class
+    // update_uv's r = (rho + rho') / 2 is that density and dt / r the host's correctly rounded dt / rho.
+    int cls = 2;
+    {
+      bool rz = true, ro = true;
 #pragma unroll
-      for (int q = 0; q < V; ++q) rhor[q] = rho_of(c, Fr[q]);
-      const T rhol = lane_up(rhor[V - 1]), pl = lane_up(pr[V - 1]);
+      for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
+      if (__all(rz)) {
+        cls = 0;
+      } else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) ro = ro && Fr[q] == (T)1;
+        if (__all(ro)) cls = 1;
+      }
+    }
+    {  // update_uv for row r (:269-280): ur / vr hold u*[r] / v*[r]
+      const T pl = lane_up(pr[V - 1]);
       const bool urow = r >= 2 && r <= nx;     // u exists on i in [2, nx]; the walls keep 0
       const bool own = r >= ra && r <= rb;     // rows this chunk stores (and counts)
+      if (cls != 2 && cls == cls1) {
+        const T k = cls ? c.dt_rho_l : c.dt_rho_g;
 #pragma unroll
-      for (int q = 0; q < V; ++q) {
-        const int j = j0 + q;
-        const T un = corrected_velocity<T>(c, ur[q], rhor[q], rho1[q], pr[q], p1[q], c.dxi);
-        ur[q] = urow ? un : (T)0;
-        const T vn = corrected_velocity<T>(c, vr[q], rhor[q], q == 0 ? rhol : rhor[q - 1], pr[q],
-                                           q == 0 ? pl : pr[q - 1], c.dyi);
-        vr[q] = (j >= 2 && j <= ny) ? vn : (T)0;   // v exists on j in [2, ny]; j = 1, ny+1 keep set_BC's 0
-        if (own && j >= jlo && j <= jhi && r >= g.own_lo && r <= g.own_hi) {
-          if (urow && ur[q] * c.dt > c.cfl_x) viol++;
-          if (j >= 2 && vr[q] * c.dt > c.cfl_y) viol++;
+        for (int q = 0; q < V; ++q) {
+          const int j = j0 + q;
+          const T un = ur[q] - k * (pr[q] - p1[q]) * c.dxi;
+          ur[q] = urow ? un : (T)0;
+          const T vn = vr[q] - k * (pr[q] - (q == 0 ? pl : pr[q - 1])) * c.dyi;
+          vr[q] = (j >= 2 && j <= ny) ? vn : (T)0;
+          p1[q] = pr[q];
         }
-        p1[q] = pr[q];
-        rho1[q] = rhor[q];
+      } else {
+        T rhor[V];
+        if (cls1 != 2) {   // the row below went through the branch above: its densities are the constant
+#pragma unroll
+          for (int q = 0; q < V; ++q) rho1[q] = cls1 ? c.rho_l : c.rho_g;
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) rhor[q] = rho_of(c, Fr[q]);
+        const T rhol = lane_up(rhor[V - 1]);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          const int j = j0 + q;
+          const T un = corrected_velocity<T>(c, ur[q], rhor[q], rho1[q], pr[q], p1[q], c.dxi);
+          ur[q] = urow ? un : (T)0;
+          const T vn = corrected_velocity<T>(c, vr[q], rhor[q], q == 0 ? rhol : rhor[q - 1], pr[q],
+                                             q == 0 ? pl : pr[q - 1], c.dyi);
+          vr[q] = (j >= 2 && j <= ny) ? vn : (T)0;   // v exists on j in [2, ny]; j = 1, ny+1 keep set_BC's 0
+          p1[q] = pr[q];
+          rho1[q] = rhor[q];
+        }
+      }
+      if (own && r >= g.own_lo && r <= g.own_hi) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          const int j = j0 + q;
+          if (j >= jlo && j <= jhi) {
+            if (urow && ur[q] * c.dt > c.cfl_x) viol++;
+            if (j >= 2 && vr[q] * c.dt > c.cfl_y) viol++;
+          }
+        }
       }
       if (own) {
         store_s<T, V>(Uo + at(g, r, j0), ur, j0, jlo, jhi);
@@ -552,6 +650,7 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
           store_c<T, V>(Uo + at(g, r + 1, j0), zero, j0, jlo, jhi);
         }
       }
+      cls1 = cls;
     }
     T out[V];
     const int io = r - 3;
@@ -559,19 +658,16 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
       // y sweep of row r in front of the pipeline; rows outside [ilo, ihi] (the ghost rows) enter
       // unswept, which is what the twin buffer holds for the x sweep in the two-kernel form
       T Fp[V];
-      bool rz = true;
-#pragma unroll
-      for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
-      if (r < ilo || r > ihi || __all(rz)) {
+      if (r < ilo || r > ihi || cls == 0) {
 #pragma unroll
         for (int q = 0; q < V; ++q) Fp[q] = Fr[q];
       } else {
         fct_y_row<T, V, false>(c, j0, ny, Fr, vr, Fp);
       }
-      pipe.template push<true>(c, r, ilo, ihi, Fp, ur, out);
+      pipe.template push<true>(c, r, ilo, ihi, Fp, ur, out, cls == 0);
     } else {
       T Fp[V];
-      pipe.template push<false>(c, r, ilo, ihi, Fr, ur, Fp);   // F'[r-3]
+      pipe.template push<false>(c, r, ilo, ihi, Fr, ur, Fp, cls == 0);   // F'[r-3]
       if (io >= ra && io <= rb) {
         bool rz = true;
 #pragma unroll

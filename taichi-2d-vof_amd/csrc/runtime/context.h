@@ -84,6 +84,7 @@ Consts<T> round_consts(const ConstsD& s) {
   R1(cfl_x); R1(cfl_y); R1(half_dx); R1(half_dy); R1(sqrt2dx); R1(tiny);
   // RN(1/b) in T arithmetic for div_by_const
   c.inv_dx = (T)1 / c.dx; c.inv_dy = (T)1 / c.dy; c.inv_dt = (T)1 / c.dt; c.inv_dxdy = (T)1 / c.dxdy;
+  c.dt_rho_l = c.dt / c.rho_l; c.dt_rho_g = c.dt / c.rho_g;   // IEEE quotients in T, as the device's dt / r
   R1(ic1_x2); R1(ic1_y2); R1(ic_r); R1(ic_cx); R1(ic2_cy); R1(ic3_cy); R1(ic3_pool);
 #undef R1
   return c;
@@ -162,7 +163,7 @@ struct vof2d_ctx {
   static constexpr int kStepBatches = 2;
   static constexpr int kStepBatch[kStepBatches] = {8, 2};   // (32 measured no better than 8)
   hipGraphExec_t gbatch[kStepBatches][2][2] = {};   // [batch size][parity of the first step][orientation]
-  bool batches_built = false;   // the batch graphs of both reachable (parity, orientation) pairs are captured together
+  bool batching = true;         // false after a failed capture of a batch: one graph launch per step from then on (build_step_batches)
   hipGraphExec_t gphase[5] = {};  // phase 0, then phases 1, 2 x istep parity (slot 2 * phase - 1 + parity)
   int next_phase = 0;
   bool f_ghosts_dirty = true;  // F's ghost cells may not satisfy set_BC (after set_init_F / from_numpy / a single verb)

@@ -163,7 +163,7 @@ struct L {
   }
   // fused normals + kappa + predictor + rhs (vof_step only)
   static void momentum(vof2d_ctx* h, bool virt = false, int adapt_par = -1) {
-    constexpr int Wt = 64 * V, Ht = ((2 + V - 1) / V) * V, ST = Wt - 2 * Ht;
+    constexpr int Wt = 64 * V, Ht = TileHalo::momentum, ST = Wt - 2 * Ht;   // must match the kernel
     const int ntt = (h->g.ny + ST - 1) / ST;
     // one residency round while that keeps the chunks short (strips, small grids); on large grids
     // several rounds of 14-row chunks beat one round of long ones (4096^2: 184 vs 195 us, 8192^2:
@@ -171,11 +171,7 @@ struct L {
     int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, resident_waves(h, k_momentum<T, V>), 4, 64);
     if (h->mom_rows <= 0 && R > 32) R = 14;
     const TbPlan tp = tb_plan(h, adapt_par);   // (one extra block: the planner wave)
-#ifdef VOF_VSTACK
-    const unsigned mom_blocks = (unsigned)ntt * (unsigned)(((h->g.ihi - h->g.ilo + R) / R + 3) / 4);
-#else
     const unsigned mom_blocks = blocks_for(h, ntt, R);
-#endif
     launch(h, kMomentum, k_momentum<T, V>, dim3(mom_blocks + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
            (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
            virt ? 1 : 0, tp);
@@ -302,11 +298,7 @@ struct L {
     RowRanges rr;
     if (ranges) rr = *ranges;
     else rr = RowRanges{{h->g.ilo, 1, 1}, {h->g.ihi, 0, 0}, {transport_rows(h), 1, 1}};
-#ifdef VOF_VSTACK
-    const unsigned tr_blocks = (unsigned)(((range_chunks(rr) + 3) / 4) * h->nty);
-#else
     const unsigned tr_blocks = (unsigned)((range_chunks(rr) * h->nty + 3) / 4);
-#endif
     launch(h, kTransport, k_transport<T, V, YFIRST>, dim3(tr_blocks), 0, h->g, C(h),
            (const T*)F_<T>(h, fF), F_<T>(h, fF2), h->nty, (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS),
            (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, rr);

@@ -223,7 +223,7 @@ void destroy_graphs(vof2d_ctx* h) {
     for (int k = 0; k < 2; ++k)
       for (int o = 0; o < 2; ++o)
         if (h->gbatch[b][k][o]) { (void)hipGraphExecDestroy(h->gbatch[b][k][o]); h->gbatch[b][k][o] = nullptr; }
-  h->batches_built = false;
+  h->batching = true;   // (a parameter change may be what a capture tripped over: try again)
   for (int k = 0; k < 5; ++k)
     if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }
 }

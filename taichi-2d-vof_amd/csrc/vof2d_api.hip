@@ -57,7 +57,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   g.own_lo = d->own_lo; g.own_hi = d->own_hi;
   g.wall_lo = d->row_lo == 0; g.wall_hi = d->row_hi == d->nx + 1;
   g.ntj = (d->ny + W - 1) / W;
-  h->nty = (d->ny + (W - 8) - 1) / (W - 8);
+  h->nty = (d->ny + (W - 2 * TileHalo::transport) - 1) / (W - 2 * TileHalo::transport);
   const int align = 128 / (int)h->esz;  // elements per 128 bytes
   g.col0 = align - 1;                   // j = 1 lands on a 128-byte boundary
   // furthest column any lane touches: the overlapped tiles of k_fct_y / k_jacobi_tb start at most
@@ -212,6 +212,45 @@ int vof_post_process_f(vof2d_handle h) {
   return ensure_ok(h);
 }
 
+// The batch graphs (kStepBatch[b] steady-state steps per launch) of the (parity, orientation) pair the current step
+// finds and of the pair the next step will find -- the two pairs a run alternates between; a handle whose parity
+// was moved alone (vof_set_istep) gets the other two on its next steady-state step.  Captures enqueue nothing.  Any
+// failure on the way ends the capture, puts the F / twin pair back, switches batching off for the handle and leaves
+// the single-step graphs (or eager launches) to carry on: never an error of vof_step.
+static void build_step_batches(vof2d_ctx* h) {
+  void* const f0 = h->fld[fF];
+  void* const f1 = h->fld[fF2];
+  bool ok = true;
+  for (int c = 0; c < 2 && ok; ++c) {
+    if (c) swap_F(h);                                   // the pair as the NEXT step will find it
+    const int64_t first = h->istep + c;
+    const int ori_c = h->fld[fF] == h->f_home ? 0 : 1;
+    for (int b = 0; b < vof2d_ctx::kStepBatches && ok; ++b) {
+      hipGraphExec_t& slot = h->gbatch[b][(int)(first & 1)][ori_c];
+      if (slot) continue;
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { ok = false; break; }
+      for (int k = 0; k < vof2d_ctx::kStepBatch[b]; ++k)
+        DISPATCH_T(h, enqueue_step<double>(h, first + k, true, true), enqueue_step<float>(h, first + k, true, true));
+      hipError_t e = hipStreamEndCapture(h->stream, &graph);          // (always: the stream must leave capture mode)
+      if (e == hipSuccess) e = hipGraphInstantiate(&slot, graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) { slot = nullptr; ok = false; break; }
+      (void)hipGraphUpload(slot, h->stream);     // so that the first replay -- possibly inside a timed region -- does not pay for it
+    }
+    h->fld[fF] = f0;                             // whatever the captured steps did to the host's view of the pair
+    h->fld[fF2] = f1;
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    for (int b = 0; b < vof2d_ctx::kStepBatches; ++b)
+      for (int k = 0; k < 4; ++k)
+        if (h->gbatch[b][k >> 1][k & 1]) { (void)hipGraphExecDestroy(h->gbatch[b][k >> 1][k & 1]); h->gbatch[b][k >> 1][k & 1] = nullptr; }
+    h->batching = false;
+    if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] step batches could not be captured: one graph launch per step\n");
+  }
+}
+
 int vof_step(vof2d_handle h, int64_t nsteps) {
   if (!h) return VOF_EINVAL;
   if (nsteps < 0) return fail(h, VOF_EINVAL, "nsteps must be >= 0");
@@ -237,29 +276,7 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       // Parity and orientation flip together from step to step, so two (parity, orientation) pairs are
       // reachable; the batch graphs of both are captured the first time a steady-state step comes by (captures
       // enqueue nothing), so that no later call pays for an instantiation in the middle of a run.
-      if (!h->batches_built) {
-        for (int c = 0; c < 2; ++c) {
-          if (c) swap_F(h);                                   // the pair as the NEXT step will find it
-          const int64_t first = h->istep + c;
-          const int ori_c = h->fld[fF] == h->f_home ? 0 : 1;
-          for (int b = 0; b < vof2d_ctx::kStepBatches; ++b) {
-            hipGraph_t graph = nullptr;
-            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            for (int k = 0; k < vof2d_ctx::kStepBatch[b]; ++k)
-              DISPATCH_T(h, enqueue_step<double>(h, first + k, true, true), enqueue_step<float>(h, first + k, true, true));
-            HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
-            hipError_t e = hipGraphInstantiate(&h->gbatch[b][(int)(first & 1)][ori_c], graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (e != hipSuccess) {
-              snprintf(h->err, sizeof(h->err), "hipGraphInstantiate: %s", hipGetErrorString(e));
-              if (c) swap_F(h);
-              return VOF_EHIP;
-            }
-          }
-          if (c) swap_F(h);
-        }
-        h->batches_built = true;
-      }
+      if (h->batching && !h->gbatch[0][par][h->fld[fF] == h->f_home ? 0 : 1]) build_step_batches(h);
       const int ori = h->fld[fF] == h->f_home ? 0 : 1;
       bool batched = false;
       for (int b = 0; b < vof2d_ctx::kStepBatches && !batched; ++b) {
@@ -289,8 +306,10 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) {
           snprintf(h->err, sizeof(h->err), "hipGraphInstantiate: %s", hipGetErrorString(e));
+          if (one_swap) swap_F(h);
           return VOF_EHIP;
         }
+        (void)hipGraphUpload(h->gexec[par][ori], h->stream);
         if (one_swap) swap_F(h);   // capturing ran enqueue_step, which swapped the host's view: undo, redo below
       }
       HIPCHK(h, hipGraphLaunch(h->gexec[par][ori], h->stream));

@@ -36,6 +36,7 @@ struct Consts {
   T dt, dx, dy, dxi, dyi, dxi2, dyi2, rho_l, rho_g, nu_l, nu_g, sigma, gx, gy;
   T nrm_x, nrm_y, kap_x, kap_y, dxdy, dtdy, dtdx, cfl_x, cfl_y, half_dx, half_dy, sqrt2dx, tiny;
   T inv_dx, inv_dy, inv_dt, inv_dxdy;  // correctly rounded reciprocals (div_by_const)
+  T dt_rho_l, dt_rho_g;                // dt / rho_l, dt / rho_g: update_uv's dt / r (2dvof.py:273) where both cells hold pure liquid / gas
   // set_init_F literals (2dvof.py:141-159), folded in double then rounded
   T ic1_x2, ic1_y2, ic_r, ic_cx, ic2_cy, ic3_cy, ic3_pool;
 };
@@ -45,6 +46,13 @@ struct Consts {
 // residency round allows, so the lead-in rows of every chunk weigh twice as much: fp32 at 4096^2
 // 601 us/step with V = 4, 443 us/step with V = 2; 2048^2 249 -> 174 us.)
 template <typename T> struct VecWidth { static constexpr int V = 2; };
+
+// Columns on each side of a 64*V-column tile that k_momentum / the FCT y stage load and compute but do not store
+// (the neighbouring tile does).  The stencils need 2 and 4; 8 makes the tile stride 112 columns = 7 cache lines of
+// doubles, so every tile's stored segment starts and ends on a 128-byte line (on a 64-byte sector in fp32).  With
+// strides of 124 / 120 columns two waves -- often on different CUs -- each write part of the line between their tiles:
+// the compute-free skeletons of the two kernels (tools/probes/stream_pattern.hip) run 11 % / 7 % faster at 112.
+struct TileHalo { static constexpr int momentum = 2, transport = 8; };
 
 template <typename T, int V>
 struct alignas(sizeof(T) * V) Pack {

@@ -39,7 +39,8 @@ def build_parser():
                      help='call the kernels one by one exactly as the main loop :513-528 does, instead of the fused '
                           'vof_step() schedule (same results, more HBM traffic; one GPU)')
     ext.add_argument('--jacobi-tol', type=float, default=0.0,
-                     help='residual-terminated pressure solve instead of the fixed sweep count (one GPU), capped by --jacobi-max')
+                     help='residual-terminated pressure solve instead of the fixed sweep count, capped by --jacobi-max '
+                          '(with --gpus N the two norms are all-reduced over the strips)')
     ext.add_argument('--jacobi-max', type=int, default=2000)
     ext.add_argument('--jacobi-crit', choices=['abs', 'rel'], default='abs',
                      help='abs: max|p_new-p| <= tol (default); rel: max|p_new-p| / max|p_new| <= tol (vof_solve_p)')
@@ -54,19 +55,36 @@ def build_parser():
     return parser
 
 
-def save_state(path, fields, istep, nx, ny, dtype, ic, courant=0):
+def numerics_of(args, dt):
+    """What, besides the fields, decides how a run continues: a checkpoint resumed with other values of these is
+    a different run, not a continuation."""
+    return {"dt": float(dt), "jacobi_iters": int(args.jacobi_iters), "coord_cast": str(args.coord_cast),
+            "jacobi_tol": float(args.jacobi_tol), "jacobi_max": int(args.jacobi_max) if args.jacobi_tol > 0.0 else 0,
+            "jacobi_crit": str(args.jacobi_crit) if args.jacobi_tol > 0.0 else ""}
+
+
+def save_state(path, fields, istep, nx, ny, dtype, ic, courant=0, numerics=None):
     tmp = path + ".tmp.npz"
+    extra = {"num_" + k: np.array(v) for k, v in (numerics or {}).items()}
     np.savez(tmp, istep=np.int64(istep), nx=np.int64(nx), ny=np.int64(ny), dtype=np.array(dtype), ic=np.int64(ic),
-             courant_violations=np.int64(courant), **fields)
+             courant_violations=np.int64(courant), **extra, **fields)
     os.replace(tmp, path)
 
 
-def load_state(path, nx, ny, dtype):
+def load_state(path, nx, ny, dtype, numerics=None):
+    """(fields, istep, courant_violations).  Refuses a file of another grid / precision, and one written with other
+    numerics (dt, sweep count, coordinate cast, residual criterion) than this run's: the tests promise an exact
+    continuation.  Files from before the numerics were recorded are accepted as they are."""
     z = np.load(path, allow_pickle=False)
     if (int(z["nx"]), int(z["ny"]), str(z["dtype"])) != (nx, ny, dtype):
         raise SystemExit("--resume: %s holds a %dx%d %s run, this one is %dx%d %s" %
                          (path, int(z["nx"]), int(z["ny"]), str(z["dtype"]), nx, ny, dtype))
-    return {f: z[f] for f in STATE}, int(z["istep"])
+    for k, v in (numerics or {}).items():
+        key = "num_" + k
+        if key in z.files and z[key].item() != v:
+            raise SystemExit("--resume: %s was written with %s = %r, this run has %r (pass the same value to continue it)" %
+                             (path, k.replace("_", "-"), z[key].item(), v))
+    return {f: z[f] for f in STATE}, int(z["istep"]), int(z["courant_violations"]) if "courant_violations" in z.files else 0
 
 
 class _Single:
@@ -78,14 +96,16 @@ class _Single:
         self.sim = VOF2D(args.nx, args.ny, dtype=args.dtype, coord_cast=args.coord_cast, device=args.device,
                          jacobi_iters=args.jacobi_iters, api=api, **consts)
         self.eng, self.rank, self.args = self.sim.eng, 0, args
+        self.base_courant = 0
 
     def init(self, ic):
         self.sim.set_init_F(ic)
 
-    def load(self, fields, istep):
+    def load(self, fields, istep, courant=0):
         for f in STATE:
             self.eng.set(f, fields[f])
         self.eng.istep = istep
+        self.base_courant = courant                  # (the device counter restarts at zero)
 
     def advance(self, n):
         a, sim = self.args, self.sim
@@ -105,7 +125,7 @@ class _Single:
         return self.eng.get(name)
 
     def courant(self):
-        return self.sim.courant_violations
+        return self.base_courant + self.sim.courant_violations
 
     def close(self):
         self.sim.sync()
@@ -121,26 +141,41 @@ class _Strips:
         self.s = StripSolver(args.nx, args.ny, args.dtype, ic=args.ic, coord_cast=args.coord_cast,
                              jacobi_iters=args.jacobi_iters, rank=rank, world=world, device=rank, api=api,
                              comm=comm, dist=getattr(comm, "dist", None), **consts)
-        self.eng, self.rank, self.world = self.s.eng, rank, world
+        self.eng, self.rank, self.world, self.args = self.s.eng, rank, world, args
+        self.base_courant = 0
 
     def init(self, ic):
         pass                                         # StripSolver ran set_init_F on its strip
 
-    def load(self, fields, istep):
+    def load(self, fields, istep, courant=0):
         lo, hi = self.s.rows
         for f in STATE:
             self.eng.set(f, fields[f][lo:hi + 1])   # every rank reads the file: owned rows and halos alike
         self.eng.istep = istep
+        self.base_courant = courant                  # (the device counters restart at zero)
 
     def advance(self, n):
-        self.s.step(n)
+        a = self.args
+        if a.jacobi_tol <= 0.0:
+            self.s.step(n)
+            return
+        e = self.eng
+        for _ in range(n):   # main loop :513-528, verb by verb on the extended strip, with the residual-terminated solve
+            e.istep = e.istep + 1
+            e.cal_nu_rho(); e.get_normal_young(); e.advect_upwind(); e.set_BC()
+            # (StripSolver.solve_p: the sweeps of a check in batches the deep halo of p covers, p exchanged after every
+            # batch, both norms all-reduced (MAX) -- same sweep counts and residuals as vof_solve_p on one domain)
+            self.s.solve_p(a.jacobi_tol, a.jacobi_max, 10, a.jacobi_crit)
+            e.update_uv(); e.set_BC()
+            e.solve_VOF_rudman(e.istep); e.post_process_f(); e.set_BC()
+            self.s.exchange()                         # F, u, v, p: the 8 rows the step consumed are well inside the halo
 
     def full(self, name):
         return self.s.gather(name)                   # rank 0: (nx+2, ny+2); others: None
 
     def courant(self):
         parts = self.s.comm.gather_object(int(self.eng.get_counter("courant_violations")))
-        return sum(parts) if self.rank == 0 else 0
+        return self.base_courant + sum(parts) if self.rank == 0 else 0
 
     def close(self):
         self.s.barrier()
@@ -152,11 +187,16 @@ def run(args, api=None, comm=None, rank=None, world=None, out=None):
     engine in the product).  comm / rank / world: the process group when several ranks run."""
     say = out if out is not None else (lambda *a: print(*a, flush=True))
     if world is None:
-        world = int(os.environ.get("WORLD_SIZE", 1)) if args.gpus > 1 else 1
+        env_world = int(os.environ.get("WORLD_SIZE", 1))
+        if args.gpus == 1 and env_world > 1:
+            # e.g. torchrun without --gpus: every rank would run the whole problem on device 0 and race on output/, data/
+            raise SystemExit("started under a launcher with WORLD_SIZE = %d but --gpus is 1: pass --gpus %d (row strips), "
+                             "or start a single process" % (env_world, env_world))
+        world = env_world if args.gpus > 1 else 1
     if rank is None:
         rank = int(os.environ.get("RANK", 0)) if world > 1 else 0
-    if world > 1 and (args.verbs or args.jacobi_tol > 0.0 or args.vis):
-        raise SystemExit("--verbs, --jacobi-tol and --vis run on one GPU (drop --gpus)")
+    if world > 1 and (args.verbs or args.vis):
+        raise SystemExit("--verbs and --vis run on one GPU (drop --gpus)")
     if world > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if api is None:
@@ -189,9 +229,10 @@ def run(args, api=None, comm=None, rank=None, world=None, out=None):
     if lead:
         os.makedirs('output', exist_ok=True)  # Make dir for output                 (:500)
         os.makedirs('data', exist_ok=True)    # Make dir for data save               (:501)
+    numerics = numerics_of(args, dt)
     if args.resume:
-        fields, istep = load_state(args.resume, nx, ny, args.dtype)
-        drv.load(fields, istep)
+        fields, istep, warn0 = load_state(args.resume, nx, ny, args.dtype, numerics)
+        drv.load(fields, istep, warn0)
         if lead:
             say(f'>>> Resumed from {args.resume} at step {istep}.')
 
@@ -212,7 +253,7 @@ def run(args, api=None, comm=None, rank=None, world=None, out=None):
                 fields = {f: drv.full(f) for f in STATE}
                 warn = drv.courant()
                 if lead:
-                    save_state('data/%08d.npz' % istep, fields, istep, nx, ny, args.dtype, args.ic, warn)
+                    save_state('data/%08d.npz' % istep, fields, istep, nx, ny, args.dtype, args.ic, warn, numerics)
             if (istep % nstep) == 0:  # Output data every <nstep> steps            (:530)
                 warn = drv.courant()
                 Fnp = drv.full("F") if args.s else None

@@ -14,8 +14,8 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nx", "512", "--steps", "6", "--warmup", "2",
-                        "--jacobi-sweeps-timed", "20", "--cpu-seconds", "0.5", "--sustained-steps", "200"], capture_output=True, text=True,
-                       timeout=600)
+                        "--jacobi-sweeps-timed", "20", "--cpu-seconds", "0.5", "--sustained-steps", "200", "--profile-steps", "14"],
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -24,11 +24,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["unit"] == "cell-updates/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert abs(d["value"] - 512 * 512 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
-    rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    rf = d["roofline"]                             # the Jacobi kernel the step runs, from the in-situ profile
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_jacobi_tb"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["algorithmic_bytes_per_launch"] == 3 * 8 * 512 * 512
-    assert "traffic" in rf and isinstance(rf["traffic_note"], str)
+    assert rf["algorithmic_bytes_per_launch"] == 3 * 8 * 512 * 512 and rf["sweeps_per_launch"] == 5
+    assert "traffic" in rf and isinstance(rf["traffic_note"], str) and "in-situ profile, 14 steps" in rf["duration_source"]
+    assert abs(rf["us_per_launch"] - d["step_kernels"]["k_jacobi_tb"]["us_per_launch_dispatch"]) < 1e-9
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"]
+    one = rf["north_star_single_sweep"]            # the single-sweep kernel of the north star's wording: a sub-record
+    assert one["kernel"] == "k_jacobi" and abs(one["frac"] - one["achieved"] / 8000.0) < 1e-12 and one["us_per_launch"] > 0
     low = rf["in_step_lowest"]                     # the kernel of the step itself that is furthest below the peak
     assert low["kernel"] in ("k_momentum", "k_jacobi_tb", "k_transport") and abs(low["frac_of_peak"] - low["achieved"] / 8000.0) < 1e-12
     assert low["frac_of_peak"] == min(v["frac_of_peak"] for v in d["step_kernels"].values())
@@ -47,11 +51,26 @@ def test_bench_default_workload_reports_the_1024_residual_solve():
     """BASELINE configs[1] as a bench leg (small step counts elsewhere to keep it short)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
                         "--jacobi-sweeps-timed", "20", "--no-cpu-baseline", "--no-scaling-reference",
-                        "--sustained-steps", "100"], capture_output=True, text=True, timeout=900)
+                        "--sustained-steps", "100", "--profile-steps", "12"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
     rs = d["residual_solve_1024"]
     assert rs["converged"] and rs["residual"] <= 1e-6 and 100000 <= rs["iterations"] < 3000000 and rs["sweeps_per_s"] > 1e4
+
+
+def test_bench_defaults_time_a_window_of_at_least_200_steps():
+    """One headline, not two: the default timed window is long enough (0.12 s at 4096^2) that it and the 1000-step
+    `sustained` record tell the same story; the in-situ profile behind `roofline` reaches into the tiny-value front."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.steps >= 200 and a.warmup >= 2 and a.profile_steps >= 300 and a.gpus == 1
 
 
 def test_bench_refuses_a_gpu_count_that_does_not_match_the_launcher():

@@ -68,6 +68,59 @@ def test_resume_continues_the_run_exactly(tmp_path, world):
     assert not (tmp_path / "b" / "data" / "00000050.npz").exists()
 
 
+def test_two_ranks_with_a_residual_terminated_solve_equal_one(tmp_path):
+    """`--gpus 2 --jacobi-tol`: the pressure solve of every step runs until the GLOBAL residual is below the tolerance
+    (2dvof.py:521-522 has a fixed count; extension) -- norms all-reduced over the strips, p exchanged between the sweep
+    batches -- and ends after the same number of sweeps as on one domain: same fields, same PNG bytes."""
+    args = ["-ic", "2", "-s", "--nx", "64", "--ny", "48", "--dtype", "f64", "--steps", "100", "--save-every", "50",
+            "--jacobi-tol", "2e-3", "--jacobi-max", "60", "--jacobi-crit", "abs"]
+    out1 = _run(tmp_path / "w1", 1, args)
+    out2 = _run(tmp_path / "w2", 2, args + ["--gpus", "2"])
+    assert ">>> Number of steps:100" in out1 and ">>> Number of steps:100" in out2
+    a = (tmp_path / "w1" / "output" / "000000-f.png").read_bytes()
+    assert len(a) > 1000 and a == (tmp_path / "w2" / "output" / "000000-f.png").read_bytes()
+    for st in (50, 100):
+        z1 = np.load(tmp_path / "w1" / "data" / ("%08d.npz" % st))
+        z2 = np.load(tmp_path / "w2" / "data" / ("%08d.npz" % st))
+        for f in ("F", "u", "v", "p"):
+            assert np.array_equal(z1[f], z2[f]), (st, f)
+        assert float(z1["num_jacobi_tol"]) == 2e-3 and int(z2["num_jacobi_max"]) == 60
+    # and the tolerance really decides the sweep count: a run with the reference's fixed ten sweeps differs
+    _run(tmp_path / "w3", 1, [x for x in args if x not in ("--jacobi-tol", "2e-3", "--jacobi-max", "60", "--jacobi-crit", "abs")])
+    z3 = np.load(tmp_path / "w3" / "data" / "00000100.npz")
+    assert not np.array_equal(np.load(tmp_path / "w1" / "data" / "00000100.npz")["p"], z3["p"])
+
+
+def test_resume_refuses_other_numerics(tmp_path):
+    """A checkpoint records dt, the sweep count, the coordinate cast and the residual criterion; resuming it with other
+    values is refused instead of silently continuing a different run.  The Courant count travels with it."""
+    base = ["-ic", "1", "--nx", "40", "--ny", "40", "--dtype", "f64", "--save-every", "20", "--steps", "40"]
+    _run(tmp_path / "a", 1, base + ["--jacobi-iters", "8"])
+    ck = str(tmp_path / "a" / "data" / "00000020.npz")
+    z = np.load(ck)
+    assert int(z["num_jacobi_iters"]) == 8 and float(z["num_dt"]) == 4e-6 and str(z["num_coord_cast"]) == "f32"
+    from vof2d import cli
+    p = cli.build_parser()
+    for extra, what in ((["--jacobi-iters", "10"], "jacobi-iters"), (["--jacobi-iters", "8", "--dt", "2e-6"], "dt"),
+                        (["--jacobi-iters", "8", "--coord-cast", "none"], "coord-cast")):
+        with pytest.raises(SystemExit) as e:
+            cli.load_state(ck, 40, 40, "f64", cli.numerics_of(p.parse_args(base + extra), 2e-6 if "--dt" in extra else 4e-6))
+        assert what in str(e.value)
+    fields, istep, warn = cli.load_state(ck, 40, 40, "f64", cli.numerics_of(p.parse_args(base + ["--jacobi-iters", "8"]), 4e-6))
+    assert istep == 20 and warn == int(z["courant_violations"]) and fields["F"].shape == (42, 42)
+
+
+def test_a_launcher_without_gpus_flag_is_refused(monkeypatch):
+    """Under torchrun with WORLD_SIZE > 1 but --gpus 1 every rank would run the whole problem on device 0 and race on
+    output/ and data/: refused before any engine is made."""
+    from vof2d import cli
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "1")
+    with pytest.raises(SystemExit) as e:
+        cli.run(cli.build_parser().parse_args(["--steps", "1"]), api=object())
+    assert "--gpus 4" in str(e.value)
+
+
 def test_flags_of_the_reference_and_refusals():
     from vof2d import cli
     p = cli.build_parser()
@@ -77,6 +130,8 @@ def test_flags_of_the_reference_and_refusals():
         p.parse_args(["-ic", "4"])
     with pytest.raises(SystemExit):       # the single-GPU extensions are refused on strips, before any engine is made
         cli.run(p.parse_args(["--gpus", "2", "--verbs"]), api=object(), rank=0, world=2)
+    with pytest.raises(SystemExit):
+        cli.run(p.parse_args(["--gpus", "2", "--vis", "3"]), api=object(), rank=0, world=2)
     with pytest.raises(SystemExit):
         cli.run(p.parse_args(["--gpus", "2"]), api=object(), rank=0, world=3)
 

@@ -4,8 +4,9 @@
 T=${1:-r04}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 RUN="python3 tools/bound_run.py $*"
-pass() {  # name, counters...
+pass() {  # name, counters...   (PASSES="insts cycles" in the environment: only those)
   n=$1; shift
+  if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $n "; then return; fi
   rm -rf gpurun_out/${T}_bound_$n
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/${T}_bound_$n -- $RUN > gpurun_out/${T}_bound_$n.log 2>&1
   echo "pass $n: rc $? $(tail -2 gpurun_out/${T}_bound_$n.log | cut -c1-200)"
