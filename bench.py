@@ -72,7 +72,7 @@ def parse():
                          "or by torch.distributed P2P")
     ap.add_argument("--attempt-timeout", type=float, default=0.0,
                     help="N > 1: seconds one attempt (native, then torch) may take before the supervising process "
-                         "kills it and tries the next carrier (default 300 + 0.01 per step; three times that for torch)")
+                         "kills it and tries the next carrier (default 120 + 0.05 per step; three times that for torch)")
     ap.add_argument("--no-supervisor", action="store_true", help="N > 1: run in this process, no watchdog / fallback")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--fast-leg", action="store_true", help=argparse.SUPPRESS)
@@ -243,9 +243,10 @@ def supervise(a, rank):
     (VOF2D_RDZV_TAG) and the attempt number."""
     import signal
     carriers = ["native", "torch"] if a.exchange == "native" else ["torch"]
-    # generous: on a fresh box the first load of the HIP runtime and of RCCL (a 570 MB library) can
-    # take a minute; the limit only matters if the attempt hangs
-    limit = a.attempt_timeout if a.attempt_timeout > 0 else 300.0 + 0.01 * (a.steps + a.warmup)
+    # the limit only matters if the attempt hangs.  Fixed part: on a fresh box the first load of the HIP runtime and of
+    # RCCL (a 570 MB library) and ncclCommInitRank can take a minute; proportional part: 50 ms per step is ~100 x what
+    # a strip step takes (0.35 ms), and covers the cost probe, the re-cut and the same-grid single-GPU reference leg
+    limit = a.attempt_timeout if a.attempt_timeout > 0 else 120.0 + 0.05 * (a.steps + a.warmup)
     argv = [x for x in sys.argv[1:] if x not in ("--child",)]
     # drop a user-given --exchange (the attempt decides), keep everything else
     cleaned, skip = [], False
@@ -692,6 +693,12 @@ def main():
     except Exception:
         one_kernel_transport = False
     ARRAYS_PER_STEP = ARRAYS_PER_STEP_FULL if one_kernel_transport else ARRAYS_PER_STEP_STRIP
+    if rank == 0 and dist_path:
+        # which carrier moved the halos, BEFORE the line (a reader of the log sees it even if the line is lost)
+        print("[bench] carrier: %s exchange, overlap mode %s%s, %s" % (
+            exchange, a.overlap, "" if effective_overlap == a.overlap else " requested but ran as mode %s" % effective_overlap,
+            ("%s of %d timed steps replayed from the captured exchange graph" % (graph_steps, a.steps)) if graph_steps is not None
+            else "eager launches"), file=sys.stderr, flush=True)
     if rank == 0:
         out = {
             "metric": "cell-updates/sec (whole node), %dx%d %s dam-break" % (nx, ny, "fp64" if esz == 8 else "fp32"),

@@ -99,6 +99,37 @@ template <typename T, int V>
 __device__ __forceinline__ void store_s(T* __restrict__ p, const T (&c)[V], int j0, int jlo, int jhi) {
   store_c_nt<T, V>(p, c, j0, jlo, jhi);
 }
+// Lane-masked streaming store WITHOUT a branch: a raw buffer store whose lanes carry a byte offset into a 2 GiB
+// window behind `base` (wave-uniform); a lane whose offset is kBufSkip lies outside the window and the hardware
+// drops its write.  Unlike an exec-masked global store (which the compiler wraps in an s_cbranch_execz it then
+// cannot count) this is one unconditional memory instruction, so the s_waitcnt counts of a software-pipelined loop
+// stay exact: waiting for the rows requested an iteration ago does not also wait for the stores issued since.
+constexpr int kBufSkip = (int)0x80000000;
+// (the descriptor and the row offset live in SGPRs: values the compiler cannot prove wave-uniform would be read back
+// lane by lane in a waterfall loop around every store, so they are declared uniform here)
+template <typename T>
+__device__ __forceinline__ T* wave_uniform(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_buf_nt(const T* base, int lane_off_bytes, int row_off_bytes, const T (&c)[V]) {
+  static_assert(sizeof(T) * V == 16 || sizeof(T) * V == 8, "one b128 / b64 store per lane");
+  row_off_bytes = __builtin_amdgcn_readfirstlane(row_off_bytes);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(wave_uniform(const_cast<T*>(base)), 0, kBufSkip, 0x00020000);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  vec_t k;
+#pragma unroll
+  for (int q = 0; q < V; ++q) k[q] = c[q];
+  if constexpr (sizeof(T) * V == 16) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, k), r, lane_off_bytes, row_off_bytes, 2 /* nt */);
+  } else {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, k), r, lane_off_bytes, row_off_bytes, 2 /* nt */);
+  }
+}
 template <typename T, int V>
 __device__ __forceinline__ T left_of(const Row<T, V>& w, int q) { return q == 0 ? w.l : w.c[q - 1]; }
 template <typename T, int V>

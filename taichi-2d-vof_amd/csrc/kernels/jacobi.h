@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256) void k_jacobi(Geom g, Consts<T> c, const T* __
 // max|p_TS| over the owned cells the tile stores, so the residual-terminated solve keeps the TS-sweep
 // fusion.  p_(TS-1) of a row is the previous stage's output one iteration earlier (kept in V extra
 // registers when SQ, where the ring holds products rather than values).
-template <typename T, int V, int TS, bool SQ, bool RESID = false>
+// BS (even ny, fields below 2 GiB; chosen by the launch wrapper): unconditional loads and a range-checked buffer store
+// (store_buf_nt), so that the compiler's waits are exact counts -- see k_momentum.
+template <typename T, int V, int TS, bool SQ, bool RESID = false, bool BS = false>
 __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
                                                     const T* __restrict__ rhs, T* __restrict__ pn, int R,
                                                     int ntt, unsigned long long* __restrict__ norm_bits = nullptr,
@@ -233,6 +235,8 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
   }
   load_s<T, V>(rq[0], rowptr(rhs, t0 - 1));
 
+  const T* const pn_tile = pn + (int64_t)(g.col0 + c0);   // BS: (wave-uniform) the tile's first column of stored row row_lo
+  const int voff_st = (j0 >= jlo && j0 + V - 1 <= jhi) ? lane * (int)(V * sizeof(T)) : kBufSkip;
   auto sub = [&](auto uc, int t) {
     constexpr int U = decltype(uc)::value;
     constexpr int kM = U % 3, kC = (U + 1) % 3, kE = (U + 2) % 3;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
             if (j0 + q >= jlo && j0 + q <= jhi) norm_acc<T>(upd, pmx, carry[q], SQ ? pv[q] : ring[TS - 1][kC][q]);
         }
       }
-      if (s == 1 && t < t1) {
+      if (s == 1 && (BS || t < t1)) {
         // ring[0][kM] (row t-2) is dead now: prefetch row t+1 into it; rhs row t into the free slot
         const T* qn = rowptr(p, t + 1);
         load_c<T, V>(ring[0][kM], qn);
@@ -311,7 +315,10 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
       }
     }
     const int io = t - TS;
-    if (io >= ra && io <= rb) store_s<T, V>(pn + at(g, io, j0), carry, j0, jlo, jhi);
+    if constexpr (BS)
+      store_buf_nt<T, V>(pn_tile, (io >= ra && io <= rb) ? voff_st : kBufSkip, (int)((int64_t)(io - g.row_lo) * pitch * (int64_t)sizeof(T)), carry);
+    else if (io >= ra && io <= rb)
+      store_s<T, V>(pn + at(g, io, j0), carry, j0, jlo, jhi);
     if constexpr (RESID && SQ) {
 #pragma unroll
       for (int q = 0; q < V; ++q) pv[q] = pv_new[q];

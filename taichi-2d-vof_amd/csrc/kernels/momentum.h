@@ -82,7 +82,12 @@ __device__ __forceinline__ void mirror_ghost_cols(Row<T, V>& w, int j0, int ny) 
   if (j0 + V == ny + 1) w.r = w.c[V - 1];
 }
 
-template <typename T, int V>
+// BS (even ny, fields below 2 GiB: chosen by the launch wrapper): every memory instruction of the row loop is
+// unconditional -- the loads run one clamped row past the chunk, the stores are range-checked buffer stores
+// (store_buf_nt) whose lanes outside [jlo, jhi] and rows outside the chunk are dropped by the hardware.  The
+// compiler then counts them, and the wait for the rows requested an iteration ago no longer includes the three
+// stores issued since: 187 -> 172 us at 4096^2 fp64 (profiles/r04_ab_buffer_stores.log).
+template <typename T, int V, bool BS>
 __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* __restrict__ F,
                                                    const T* __restrict__ u, const T* __restrict__ v,
                                                    T* __restrict__ us, T* __restrict__ vs, T* __restrict__ rhs,
@@ -141,6 +146,10 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   T us3[V], vs3[V];            // u*, v* row r-3
   T rho3[V];                   // rho(F) row r-3 (rho is a pure function of F[i,j], :201-202)
   const int r0 = ra - 1, r1 = rb + 3;
+  const T* const us_tile = us + (int64_t)(g.col0 + c0);    // BS: (wave-uniform) first column of the tile in stored row row_lo
+  const T* const vs_tile = vs + (int64_t)(g.col0 + c0);
+  const T* const rhs_tile = rhs + (int64_t)(g.col0 + c0);
+  const int voff_st = (j0 >= jlo && j0 + V - 1 <= jhi) ? lane * (int)(V * sizeof(T)) : kBufSkip;   // (even ny: no lane is cut by jlo / jhi)
   load_F(F2, r0 - 2);
   load_F(F1, r0 - 1);
   // u, v rows below ra-1 are never used by a stored value (the first stored u*, v* row is ra, which
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   for (int r = r0; r <= r1; ++r) {
     Row<T, V> F0 = Fn, u1 = un;
     const Row<T, V> v1 = vn;
-    if (r < r1) {
+    if (BS || r < r1) {    // (BS: past the chunk's last row a clamped row is loaded and never used)
       load_F(Fn, r + 1);
       load_u(un, r);
       load_v(vn, r);
@@ -263,13 +272,18 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
       us2[q] = (okP && i >= 2 && dom[q]) ? ou : (T)0;           // u* exists on i in [2, nx]
       vs2[q] = (okP && j >= 2 && j <= ny) ? ov : (T)0;          // v* exists on j in [2, ny]
     }
-    if (i >= ra && i <= rb) {
+    if constexpr (BS) {
+      const int vo = (i >= ra && i <= rb) ? voff_st : kBufSkip;
+      const int so = (int)((int64_t)(i - g.row_lo) * g.pitch * (int64_t)sizeof(T));
+      store_buf_nt<T, V>(us_tile, vo, so, us2);    // (row 1 and column 1 of v* carry the zeros the never-written entries hold)
+      store_buf_nt<T, V>(vs_tile, vo, so, vs2);
+    } else if (i >= ra && i <= rb) {
       if (i >= 2) store_s<T, V>(us + at(g, i, j0), us2, j0, jlo, jhi);
       store_s<T, V>(vs + at(g, i, j0), vs2, j0, jlo > 2 ? jlo : 2, jhi);
     }
     // ---- R: rhs of row r-3 (:239-241)
     const int i3 = r - 3;
-    if (i3 >= ra && i3 <= rb) {
+    if (BS || (i3 >= ra && i3 <= rb)) {
       const T vsr = lane_dn(vs3[0]);
       T out[V];
 #pragma unroll
@@ -279,7 +293,11 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
         out[q] = div_by_const_inrange<T>(rho3[q], c.dt, c.inv_dt) *
                  ((us2[q] - us3[q]) * c.dxi + (vright - vs3[q]) * c.dyi);
       }
-      store_s<T, V>(rhs + at(g, i3, j0), out, j0, jlo, jhi);
+      if constexpr (BS)
+        store_buf_nt<T, V>(rhs_tile, (i3 >= ra && i3 <= rb) ? voff_st : kBufSkip,
+                           (int)((int64_t)(i3 - g.row_lo) * g.pitch * (int64_t)sizeof(T)), out);
+      else
+        store_s<T, V>(rhs + at(g, i3, j0), out, j0, jlo, jhi);
     }
     // ---- shift the windows
 #pragma unroll

@@ -90,6 +90,14 @@ inline unsigned blocks_for(const vof2d_ctx* h, int ntiles, int R) {
   return (unsigned)((waves + 3) / 4);
 }
 
+// The BS form of k_momentum (range-checked buffer stores, see store_buf_nt): a lane's V columns must be stored or
+// skipped together (tiles start on odd columns, so ny must be even) and a field must fit the 32-bit byte offsets of
+// a buffer instruction.  Everything else takes the form with exec-masked global stores.  (k_transport -- which moves
+// its L2-miss traffic at 5.6 TB/s either way -- gained nothing from the same change and keeps its global stores.)
+inline bool buffer_stores_ok(const vof2d_ctx* h) {
+  return h->buf_stores && (h->g.ny % 2 == 0) && (size_t)h->field_elems * h->esz < ((size_t)1 << 31) - (1u << 20);
+}
+
 // ------------------------------------------------------------------ launches
 constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe
 enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
@@ -168,13 +176,19 @@ struct L {
     // one residency round while that keeps the chunks short (strips, small grids); on large grids
     // several rounds of 14-row chunks beat one round of long ones (4096^2: 184 vs 195 us, 8192^2:
     // 665 vs 758 us) -- the halo rows of adjacent, simultaneously resident chunks are L2 hits
-    int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, resident_waves(h, k_momentum<T, V>), 4, 64);
+    const bool bs = buffer_stores_ok(h) && (h->buf_stores & 1);
+    int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, bs ? resident_waves(h, k_momentum<T, V, true>) : resident_waves(h, k_momentum<T, V, false>), 4, 64);
     if (h->mom_rows <= 0 && R > 32) R = 14;
     const TbPlan tp = tb_plan(h, adapt_par);   // (one extra block: the planner wave)
     const unsigned mom_blocks = blocks_for(h, ntt, R);
-    launch(h, kMomentum, k_momentum<T, V>, dim3(mom_blocks + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
-           (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
-           virt ? 1 : 0, tp);
+    if (bs)
+      launch(h, kMomentum, k_momentum<T, V, true>, dim3(mom_blocks + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+             (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
+             virt ? 1 : 0, tp);
+    else
+      launch(h, kMomentum, k_momentum<T, V, false>, dim3(mom_blocks + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
+             (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
+             virt ? 1 : 0, tp);
   }
   template <bool STORED>
   static void rhs(vof2d_ctx* h) {
@@ -219,7 +233,10 @@ struct L {
     unsigned long long* none = nullptr;
     TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
     if (TS == 5 && VV == V) tp = tb_plan(h, adapt_par);
-    if (sq)
+    if (sq && buffer_stores_ok(h) && (h->buf_stores & 2))
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
+    else if (sq)
       launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
              (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
     else

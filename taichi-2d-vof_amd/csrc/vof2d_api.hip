@@ -78,10 +78,19 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
       if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = VOF_EHIP; break; }
       h->own_stream = true;
     }
+#ifdef VOF_ARENA_EXP   // placement experiment (tools/probes/arena_modes.py): shift of the whole arena, extra bytes between fields
+    const size_t shift_ = getenv("VOF2D_ARENA_SHIFT") ? (size_t)atoll(getenv("VOF2D_ARENA_SHIFT")) : 0;
+    const size_t skew_ = getenv("VOF2D_FIELD_SKEW") ? (size_t)atoll(getenv("VOF2D_FIELD_SKEW")) : 0;
+    const size_t bytes = (h->field_elems * h->esz + skew_) * NFIELDS + shift_;
+    if (hipMalloc(reinterpret_cast<void**>(&h->arena), bytes) != hipSuccess) { rc = VOF_ENOMEM; break; }
+    if (hipMemsetAsync(h->arena, 0, bytes, h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
+    for (int k = 0; k < NFIELDS; ++k) h->fld[k] = h->arena + shift_ + (size_t)k * (h->field_elems * h->esz + skew_);
+#else
     const size_t bytes = h->field_elems * h->esz * NFIELDS;
     if (hipMalloc(reinterpret_cast<void**>(&h->arena), bytes) != hipSuccess) { rc = VOF_ENOMEM; break; }
     if (hipMemsetAsync(h->arena, 0, bytes, h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     for (int k = 0; k < NFIELDS; ++k) h->fld[k] = h->arena + (size_t)k * h->field_elems * h->esz;
+#endif
     h->f_home = h->fld[fF];
     if (hipMalloc(reinterpret_cast<void**>(&h->d_courant), 4 * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
     if (hipMemsetAsync(h->d_courant, 0, 4 * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
@@ -590,7 +599,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
             : !strcmp(name, "momentum_rows") ? &h->mom_rows : !strcmp(name, "fctx_rows") ? &h->fctx_rows
             : !strcmp(name, "fctx_corr_rows") ? &h->fctx_corr_rows : !strcmp(name, "band_rows") ? &h->band_rows
             : !strcmp(name, "rows_per_wave") ? &h->rows_override : !strcmp(name, "fuse_transport") ? &h->fuse_transport
-            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : nullptr;
+            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : nullptr;
   if (knob) {
     *knob = (int)value;
     if (knob == &h->band_rows && *knob < 1) *knob = 1;

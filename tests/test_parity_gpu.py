@@ -689,3 +689,20 @@ def test_equal_cost_work_plan_of_the_fused_jacobi(hip_api, oracle_api, nx, ny, d
     # the first step has nothing to go by; from the second on the plan is in use (the grid is wide
     # enough for more than one tile column only in the larger cases -- a single column is planned too)
     assert active[0] == 0 and any(active[1:]), active
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ic,nx,ny", [("f64", 1, 640, 1024), ("f32", 2, 512, 768), ("f64", 3, 300, 250)])
+def test_buffer_stores_change_no_value(hip_api, dtype, ic, nx, ny):
+    """k_momentum / k_jacobi_tb with range-checked buffer stores (the default where ny is even) against the forms with
+    exec-masked global stores (knob buffer_stores = 0): the same cells get the same values, ghost cells included; the
+    never-written entries of u*, v* (row 1, column 1: zeros, 2dvof.py:206-233) stay zero."""
+    a = engine(hip_api, nx, ny, dtype, "f32", ic=ic)
+    b = engine(hip_api, nx, ny, dtype, "f32", ic=ic)
+    b.set_param("buffer_stores", 0)
+    for st in (1, 2, 9, 40):
+        a.step(st - a.istep)
+        b.step(st - b.istep)
+        assert_fields_same(a, b, STATE + ("u_star", "v_star", "rhs"), ctx="%s %dx%d step %d" % (dtype, nx, ny, st))
+    us, vs = a.get("u_star"), a.get("v_star")
+    assert not us[1, :].any() and not us[nx + 1, :].any() and not vs[:, 1].any() and not vs[:, ny + 1].any()
