@@ -34,6 +34,14 @@ struct WaveTimer {
 #else
 struct WaveTimer { __device__ __forceinline__ WaveTimer(int) {} };
 #endif
+// Diagnostic build only (-DVOF_SHORTCUT_STATS, tools/probes/shortcut_stats.py): how often the wave-level shortcuts of
+// k_momentum and k_transport are taken (one count per wave and row).  The product build compiles VOF_STAT to nothing.
+#ifdef VOF_SHORTCUT_STATS
+__device__ unsigned long long vof_stats[16];
+#define VOF_STAT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&vof::vof_stats[k], 1ull); } while (0)
+#else
+#define VOF_STAT(k) do { } while (0)
+#endif
 enum : int { WT_MOMENTUM = 0, WT_JACOBI_TB = 3, WT_FCT_X = 5, WT_FCT_Y = 6, WT_JACOBI = 2, WT_TRANSPORT = 12 };  // = KernelId of the runtime
 template <typename T, int V>
 struct Row {  // one row of a wave tile as seen by a lane: j0-1 | j0..j0+V-1 | j0+V

@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
     // whole wave the stage is skipped (flatF[k] caches the per-row test, one row is new per step).
     flat0 = row_flat<T, V>(F0);
     const bool flat = flat2 && flat1 && flat0 && F2.c[0] == F1.c[0] && F1.c[0] == F0.c[0];
+    VOF_STAT(0);
     if (__all(flat)) {
+      VOF_STAT(1);
 #pragma unroll
       for (int q = 0; q < V; ++q) mx1[q] = my1[q] = (T)0;
     } else {
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
       fyf[q] = -c.sigma * (F00 - F0m) * ((k00 + k0m) / (T)2.0);
       any_force = any_force || fxf[q] != (T)0 || fyf[q] != (T)0;
     }
+    if (!__any(any_force)) VOF_STAT(2);
     if (any_force) {
 #pragma unroll
       for (int q = 0; q < V; ++q) {

@@ -104,7 +104,9 @@ __device__ __forceinline__ void fct_y_row(const Consts<T>& c, int j0, int ny, co
   bool anz = an_ != (T)0;
 #pragma unroll
   for (int q = 0; q < V; ++q) anz = anz || a[q] != (T)0;
+  VOF_STAT(10);
   if (!__any(anz)) {
+    VOF_STAT(11);
 #pragma unroll
     for (int q = 0; q < V; ++q) out[q] = fct_clamp<T, POST>(td[q]);
     return;
@@ -160,6 +162,7 @@ struct FctXPipe {
   __device__ __forceinline__ void push(const Consts<T>& c, int r, int ilo, int ihi, const T (&Fr)[V],
                                        const T (&ur)[V], T (&out)[V], bool zero_row) {
     zrows = zero_row ? zrows + 1 : 0;
+    if (zrows >= 7) VOF_STAT(7);
     if (zrows >= 7) {  // the whole dependency window F[r-6..r] of the wave is zero: every output is
 #pragma unroll
       for (int q = 0; q < V; ++q) {
@@ -195,6 +198,7 @@ struct FctXPipe {
 #pragma unroll
     for (int q = 0; q < V; ++q) rp2[q] = rm2[q] = (T)0;
     const bool nzr2 = in2 && (nz2 || nz1);
+    if (in2 && !nzr2) VOF_STAT(8);
     if (nzr2) {
 #pragma unroll
       for (int q = 0; q < V; ++q) fct_ratios<T>(c, t2[q], t3[q], tn[q], a2[q], a1[q], rp2[q], rm2[q]);
@@ -208,6 +212,7 @@ struct FctXPipe {
       for (int q = 0; q < V; ++q) c2[q] = fct_climit<T>(a2[q], rp3[q], rm3[q], rp2[q], rm2[q]);
     }
     // stage D of row r-3 (faces a3 below, a2 above)
+    if (!(nz3 || nz2)) VOF_STAT(9);
     if (nz3 || nz2) {
 #pragma unroll
       for (int q = 0; q < V; ++q) out[q] = fct_final<T, POST>(c, t3[q], a3[q], c3[q], a2[q], c2[q], d3[q]);
@@ -598,7 +603,11 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
       const T pl = lane_up(pr[V - 1]);
       const bool urow = r >= 2 && r <= nx;     // u exists on i in [2, nx]; the walls keep 0
       const bool own = r >= ra && r <= rb;     // rows this chunk stores (and counts)
+      VOF_STAT(3);
+      if (cls == 0) VOF_STAT(4);
+      if (cls == 1) VOF_STAT(5);
       if (cls != 2 && cls == cls1) {
+        VOF_STAT(6);
         const T k = cls ? c.dt_rho_l : c.dt_rho_g;
 #pragma unroll
         for (int q = 0; q < V; ++q) {

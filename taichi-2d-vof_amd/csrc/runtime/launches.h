@@ -233,7 +233,12 @@ struct L {
     unsigned long long* none = nullptr;
     TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
     if (TS == 5 && VV == V) tp = tb_plan(h, adapt_par);
-    if (sq && buffer_stores_ok(h) && (h->buf_stores & 2))
+    // the buffer-store form where the launch is ONE residency round of the chunk plan (4096^2, the strips of a multi-GPU
+    // run: 105 -> 103 us, 53.7 -> 49.0 us): it needs 126 VGPRs instead of 129, i.e. four waves per SIMD are resident
+    // where the plan counted on three, which breaks the round structure of a multi-round launch (8192^2 on one GPU:
+    // 397 -> 435 us)
+    const bool one_round = (long)blocks_for(h, ntt, R) * 4 <= resident_waves(h, k_jacobi_tb<T, VV, TS, true, false>);
+    if (sq && one_round && buffer_stores_ok(h) && (h->buf_stores & 2))
       launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
              (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
     else if (sq)

@@ -118,6 +118,15 @@ int vof_destroy(vof2d_handle h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   comm_teardown(h);
   if (h->vis) (void)hipFree(h->vis);
+#ifdef VOF_SHORTCUT_STATS
+  {
+    unsigned long long a[16] = {};
+    if (hipMemcpyFromSymbol(a, HIP_SYMBOL(vof::vof_stats), sizeof(a)) == hipSuccess && a[0] + a[3])
+      fprintf(stderr, "[vof2d] shortcut stats (wave-rows): momentum rows %llu flat-normals %llu no-force %llu | transport rows %llu gas %llu liquid %llu "
+              "uniform-update_uv %llu x-pipe-zero-bypass %llu x-stageB-skipped %llu x-stageD-clamp %llu | y rows swept %llu zero-flux %llu\n",
+              a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11]);
+  }
+#endif
   if (h->d_courant) (void)hipFree(h->d_courant);
   if (h->d_tbmask) (void)hipFree(h->d_tbmask);
   if (h->arena) (void)hipFree(h->arena);

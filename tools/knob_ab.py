@@ -21,6 +21,7 @@ ap.add_argument("--dtype", default="f64")
 ap.add_argument("-ic", type=int, default=1)
 ap.add_argument("--skip", type=int, default=60)
 ap.add_argument("--lib", default="")
+ap.add_argument("--dt", type=float, default=0.0)
 a = ap.parse_args()
 from vof2d import _abi
 from vof2d._lib import hip_api
@@ -30,7 +31,7 @@ vals = [float(v) for v in a.values.split(",")]
 engs = []
 for k in range(a.engines):
     for v in vals:
-        e = Engine(api, make_desc(api, a.n, a.n, a.dtype, "f32", device=0))
+        e = Engine(api, make_desc(api, a.n, a.n, a.dtype, "f32", device=0, **({"dt": a.dt} if a.dt > 0 else {})))
         e.set_param(a.knob, v)
         e.set_init_F(a.ic)
         e.step(a.skip)
