@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
     }
     const int io = t - TS;
     if constexpr (BS)
-      store_buf_nt<T, V>(pn_tile, (io >= ra && io <= rb) ? voff_st : kBufSkip, (int)((int64_t)(io - g.row_lo) * pitch * (int64_t)sizeof(T)), carry);
+      store_buf_nt<T, V>(pn_tile, (io >= ra && io <= rb) ? voff_st : kBufSkip,
+                         (io >= ra && io <= rb) ? (int)((int64_t)(io - g.row_lo) * pitch * (int64_t)sizeof(T)) : 0, carry);   // (a dropped row keeps an in-field offset)
     else if (io >= ra && io <= rb)
       store_s<T, V>(pn + at(g, io, j0), carry, j0, jlo, jhi);
     if constexpr (RESID && SQ) {

@@ -276,8 +276,9 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
       vs2[q] = (okP && j >= 2 && j <= ny) ? ov : (T)0;          // v* exists on j in [2, ny]
     }
     if constexpr (BS) {
-      const int vo = (i >= ra && i <= rb) ? voff_st : kBufSkip;
-      const int so = (int)((int64_t)(i - g.row_lo) * g.pitch * (int64_t)sizeof(T));
+      const bool rowok = i >= ra && i <= rb;
+      const int vo = rowok ? voff_st : kBufSkip;
+      const int so = rowok ? (int)((int64_t)(i - g.row_lo) * g.pitch * (int64_t)sizeof(T)) : 0;   // (a dropped row keeps an in-field offset)
       store_buf_nt<T, V>(us_tile, vo, so, us2);    // (row 1 and column 1 of v* carry the zeros the never-written entries hold)
       store_buf_nt<T, V>(vs_tile, vo, so, vs2);
     } else if (i >= ra && i <= rb) {
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
       }
       if constexpr (BS)
         store_buf_nt<T, V>(rhs_tile, (i3 >= ra && i3 <= rb) ? voff_st : kBufSkip,
-                           (int)((int64_t)(i3 - g.row_lo) * g.pitch * (int64_t)sizeof(T)), out);
+                           (i3 >= ra && i3 <= rb) ? (int)((int64_t)(i3 - g.row_lo) * g.pitch * (int64_t)sizeof(T)) : 0, out);
       else
         store_s<T, V>(rhs + at(g, i3, j0), out, j0, jlo, jhi);
     }

@@ -697,7 +697,10 @@ def test_buffer_stores_change_no_value(hip_api, dtype, ic, nx, ny):
     """k_momentum / k_jacobi_tb with range-checked buffer stores (the default where ny is even) against the forms with
     exec-masked global stores (knob buffer_stores = 0): the same cells get the same values, ghost cells included; the
     never-written entries of u*, v* (row 1, column 1: zeros, 2dvof.py:206-233) stay zero."""
-    a = engine(hip_api, nx, ny, dtype, "f32", ic=ic)
+    canary_lo = engine(hip_api, nx, ny, dtype, "f32", ic=ic)     # bystanders allocated around the engine under test:
+    a = engine(hip_api, nx, ny, dtype, "f32", ic=ic)             # a dropped lane that was NOT dropped would land 2 GiB away,
+    canary_hi = engine(hip_api, nx, ny, dtype, "f32", ic=ic)     # or in a neighbouring allocation
+    before = [c.get(f).tobytes() for c in (canary_lo, canary_hi) for f in STATE + ("u_star", "v_star", "rhs", "pt")]
     b = engine(hip_api, nx, ny, dtype, "f32", ic=ic)
     b.set_param("buffer_stores", 0)
     for st in (1, 2, 9, 40):
@@ -706,3 +709,4 @@ def test_buffer_stores_change_no_value(hip_api, dtype, ic, nx, ny):
         assert_fields_same(a, b, STATE + ("u_star", "v_star", "rhs"), ctx="%s %dx%d step %d" % (dtype, nx, ny, st))
     us, vs = a.get("u_star"), a.get("v_star")
     assert not us[1, :].any() and not us[nx + 1, :].any() and not vs[:, 1].any() and not vs[:, ny + 1].any()
+    assert before == [c.get(f).tobytes() for c in (canary_lo, canary_hi) for f in STATE + ("u_star", "v_star", "rhs", "pt")]
