@@ -133,7 +133,9 @@ template <typename T, int V, int TS, bool SQ, bool RESID = false, bool BS = fals
 __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
                                                     const T* __restrict__ rhs, T* __restrict__ pn, int R,
                                                     int ntt, unsigned long long* __restrict__ norm_bits = nullptr,
-                                                    TbPlan tp = TbPlan{nullptr, nullptr, 0, 0, 0, 0}) {
+                                                    TbPlan tp = TbPlan{nullptr, nullptr, 0, 0, 0, 0}, int first = 1, int last = 0) {
+  // rows [first, last] of the result are produced (last < first: all of [g.ilo, g.ihi])
+  if (last < first) { first = g.ilo; last = g.ihi; }
   // SQ (dxi2 == dyi2 bitwise, i.e. square cells): the stencil has ONE off-diagonal coefficient, so
   // the product coef * p[i,j] is the same number in the equations of all four neighbours of (i,j).
   // Stages 2.. then receive products instead of values -- 1 multiply per cell-sweep instead of 4
@@ -148,11 +150,13 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
   // 2..TS, plus 1 when the first sweep also takes its j-neighbours from adjacent lanes (SQ)
   constexpr int H = ((TS - 1 + (SQ ? 1 : 0) + V - 1) / V) * V;
   constexpr int STRIDE = W - 2 * H;
-  const int wave = xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int lblock = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int wave = lblock * (blockDim.x >> 6) + wib;
   const int lane = threadIdx.x & 63;
   // wave -> (tile column tj, rows [ra, rb]): chunks of R rows of every column, or, while the tiny-value
   // front crosses the grid, the equal-cost chunks of the step's plan (tb_make_plan)
-  int tj = wave % ntt, ra = g.ilo + (wave / ntt) * R, rb = ra + R - 1;
+  int tj = 0, ra = 1, rb = 0;
   bool planned = false;
   if (tp.masks != nullptr) {
     const unsigned long long* pl = tp.plan;
@@ -164,14 +168,28 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
       planned = true;
     }
   }
+  if (!planned) {
+    // A launch sized for the whole grid's plan that produces part of the rows (enqueue_steps_halves) and finds no plan:
+    // the blocks the uniform layout needs are spread evenly over the launch's blocks, so that every XCD gets its
+    // share (the first blocks alone would all sit on half of the XCDs).
+    const int need = ((((last - first) / R + 1) * ntt) + 3) >> 2, have = (int)gridDim.x;
+    if (need < have) {
+      const int lo = (int)(((long long)lblock * need) / have), hi = (int)(((long long)(lblock + 1) * need) / have);
+      if (hi == lo) return;
+      wave = lo * (blockDim.x >> 6) + wib;
+    }
+    tj = wave % ntt; ra = first + (wave / ntt) * R; rb = ra + R - 1;
+  }
   tj = __builtin_amdgcn_readfirstlane(tj);
   ra = __builtin_amdgcn_readfirstlane(ra);
   rb = __builtin_amdgcn_readfirstlane(rb);
   if (planned && rb < ra) return;   // an unused wave of the plan
+  if (planned && ra < first) ra = first;   // (a launch on part of the rows takes its part of every planned chunk)
   const int c0 = 1 - H + tj * STRIDE;
   const int j0 = c0 + lane * V;
-  if (ra > g.ihi) return;  // wave-uniform
-  if (rb > g.ihi) rb = g.ihi;
+  if (ra > last) return;  // wave-uniform
+  if (rb > last) rb = last;
+  if (rb < ra) return;
   const int nx = g.nx, ny = g.ny;
   const int jlo = c0 + H > 1 ? c0 + H : 1;
   const int jhi = c0 + W - H - 1 < ny ? c0 + W - H - 1 : ny;

@@ -91,7 +91,8 @@ template <typename T, int V, bool BS>
 __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* __restrict__ F,
                                                    const T* __restrict__ u, const T* __restrict__ v,
                                                    T* __restrict__ us, T* __restrict__ vs, T* __restrict__ rhs,
-                                                   int R, int ntt, int virt, TbPlan tp) {
+                                                   int R, int ntt, int virt, TbPlan tp, int first, int last) {
+  // rows [first, last] (within [g.ilo, g.ihi]) are produced; the domain of the zero-ghost conventions stays [g.ilo, g.ihi]
   // the launch's FIRST block is the planner of this step's k_jacobi_tb launches (see tb_make_plan): it
   // starts with the launch and runs beside the other blocks (as the last block it would start when the
   // last slots free up and add its few microseconds to the kernel's tail)
@@ -114,9 +115,9 @@ __global__ __launch_bounds__(256) void k_momentum(Geom g, Consts<T> c, const T* 
   const int tj = wave % ntt, ch = wave / ntt;
   const int c0 = 1 - H + tj * STRIDE;
   const int j0 = c0 + lane * V;
-  const int ra = g.ilo + ch * R;
-  if (ra > g.ihi) return;  // wave-uniform
-  const int rb = ra + R - 1 < g.ihi ? ra + R - 1 : g.ihi;
+  const int ra = first + ch * R;
+  if (ra > last) return;  // wave-uniform
+  const int rb = ra + R - 1 < last ? ra + R - 1 : last;
   const int ny = g.ny, ilo = g.ilo, ihi = g.ihi;
   const int jlo = c0 + H > 1 ? c0 + H : 1;
   const int jhi = c0 + W - H - 1 < ny ? c0 + W - H - 1 : ny;

@@ -3,6 +3,7 @@
 // Part of the host-side runtime of libvof2d_hip.so; included (once, in this order) by vof2d_api.hip:
 // context.h, launches.h, schedule.h, comm.h, selftest.h.  Everything here has internal linkage.
 #pragma once
+#include <vector>
 
 #include <float.h>
 #include <hip/hip_runtime.h>
@@ -158,12 +159,20 @@ struct vof2d_ctx {
   void* f_home = nullptr;  // the buffer fld[fF] pointed to at creation (orientation of the F / twin pair)
   int phase_graph_ori = 0; // orientation the gphase / gxchg graphs were captured in
   hipGraphExec_t gexec[2][2] = {};  // whole step, [istep parity][F in its home buffer ? 0 : 1]
-  // several consecutive steady-state steps of a full domain as ONE graph (kStepBatch[b] steps, an even number: the
+  // several consecutive steady-state steps of a full domain as ONE graph (step_batch[b] steps, an even number: the
   // F / twin pair and the step parity are back where they started): a graph launch leaves ~9 us of idle queue
   // behind it, which one launch per step pays every step (vof_step)
   static constexpr int kStepBatches = 2;
-  static constexpr int kStepBatch[kStepBatches] = {8, 2};   // (32 measured no better than 8)
+  int step_batch[kStepBatches] = {8, 2};   // (32 measured no better than 8; knob "batch_steps" sets the first)
   hipGraphExec_t gbatch[kStepBatches][2][2] = {};   // [batch size][parity of the first step][orientation]
+  // knob "overlap_halves": the batch graphs run every kernel of a step as two launches, on the rows above and below a
+  // boundary that moves up by kHalvesDrift rows from kernel to kernel, the upper chain on `stream`, the lower on
+  // `stream2`; a lower launch waits for the upper launch of the kernel before it only (enqueue_steps_halves)
+  int halves = -1;   // -1: where it pays (halves_eligible), 0: never, 1: wherever the schedule allows
+  hipStream_t stream2 = nullptr;
+  bool halves_captured[2] = {false, false};   // the batch graphs of size step_batch[b] the handle holds were captured in this form
+  int64_t halves_steps = 0;       // steps replayed from them (counter "halves_steps")
+  std::vector<hipEvent_t> hev;
   bool batching = true;         // false after a failed capture of a batch: one graph launch per step from then on (build_step_batches)
   hipGraphExec_t gphase[5] = {};  // phase 0, then phases 1, 2 x istep parity (slot 2 * phase - 1 + parity)
   int next_phase = 0;

@@ -170,9 +170,11 @@ struct L {
            (const T*)F_<T>(h, fRHO), (const T*)F_<T>(h, fNU), F_<T>(h, fUS), F_<T>(h, fVS), R);
   }
   // fused normals + kappa + predictor + rhs (vof_step only)
-  static void momentum(vof2d_ctx* h, bool virt = false, int adapt_par = -1) {
+  // rows [first, last] of the predictor and the rhs (last < first: all computable rows)
+  static void momentum(vof2d_ctx* h, bool virt = false, int adapt_par = -1, int first = 1, int last = 0) {
     constexpr int Wt = 64 * V, Ht = TileHalo::momentum, ST = Wt - 2 * Ht;   // must match the kernel
     const int ntt = (h->g.ny + ST - 1) / ST;
+    if (last < first) { first = h->g.ilo; last = h->g.ihi; }
     // one residency round while that keeps the chunks short (strips, small grids); on large grids
     // several rounds of 14-row chunks beat one round of long ones (4096^2: 184 vs 195 us, 8192^2:
     // 665 vs 758 us) -- the halo rows of adjacent, simultaneously resident chunks are L2 hits
@@ -180,15 +182,15 @@ struct L {
     int R = h->mom_rows > 0 ? h->mom_rows : chunk_rows_fit(h, ntt, bs ? resident_waves(h, k_momentum<T, V, true>) : resident_waves(h, k_momentum<T, V, false>), 4, 64);
     if (h->mom_rows <= 0 && R > 32) R = 14;
     const TbPlan tp = tb_plan(h, adapt_par);   // (one extra block: the planner wave)
-    const unsigned mom_blocks = blocks_for(h, ntt, R);
+    const unsigned mom_blocks = blocks_rows(last - first + 1, ntt, R);
     if (bs)
       launch(h, kMomentum, k_momentum<T, V, true>, dim3(mom_blocks + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
              (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
-             virt ? 1 : 0, tp);
+             virt ? 1 : 0, tp, first, last);
     else
       launch(h, kMomentum, k_momentum<T, V, false>, dim3(mom_blocks + (tp.masks ? 1u : 0u)), 0, h->g, C(h), (const T*)F_<T>(h, fF),
              (const T*)F_<T>(h, fU), (const T*)F_<T>(h, fV), F_<T>(h, fUS), F_<T>(h, fVS), F_<T>(h, fRHS), R, ntt,
-             virt ? 1 : 0, tp);
+             virt ? 1 : 0, tp, first, last);
   }
   template <bool STORED>
   static void rhs(vof2d_ctx* h) {
@@ -229,24 +231,30 @@ struct L {
     return tp;
   }
   template <int TS, int VV>
-  static void jacobi_tb_launch(vof2d_ctx* h, const Consts<T>& cc, bool sq, int src, int dst, int R, int ntt, int adapt_par = -1) {
+  static void jacobi_tb_launch(vof2d_ctx* h, const Consts<T>& cc, bool sq, int src, int dst, int R, int ntt, int adapt_par = -1,
+                               int first = 1, int last = 0) {
+    if (last < first) { first = h->g.ilo; last = h->g.ihi; }
+
     unsigned long long* none = nullptr;
     TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
     if (TS == 5 && VV == V) tp = tb_plan(h, adapt_par);
+    // (with a plan the launch holds the waves of the whole grid's plan, whatever part of the rows it is for: every
+    // wave takes the part of its planned chunk inside [first, last], or nothing)
+    const unsigned nblk = tp.masks ? blocks_for(h, ntt, R) : blocks_rows(last - first + 1, ntt, R);
     // the buffer-store form where the launch is ONE residency round of the chunk plan (4096^2, the strips of a multi-GPU
     // run: 105 -> 103 us, 53.7 -> 49.0 us): it needs 126 VGPRs instead of 129, i.e. four waves per SIMD are resident
     // where the plan counted on three, which breaks the round structure of a multi-round launch (8192^2 on one GPU:
     // 397 -> 435 us)
     const bool one_round = (long)blocks_for(h, ntt, R) * 4 <= resident_waves(h, k_jacobi_tb<T, VV, TS, true, false>);
     if (sq && one_round && buffer_stores_ok(h) && (h->buf_stores & 2))
-      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false, true>, dim3(nblk), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp, first, last);
     else if (sq)
-      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false>, dim3(nblk), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp, first, last);
     else
-      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, false, false>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp);
+      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, false, false>, dim3(nblk), 0, h->g, cc,
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp, first, last);
   }
   // TS sweeps src -> dst, the last of which also reduces max|p_new - p| and max|p_new| over the owned
   // rows into d_courant[1..2] (the residual-terminated solve): same values as
@@ -264,18 +272,18 @@ struct L {
     const TbPlan notp{nullptr, nullptr, 0, 0, 0, 0};   // uniform layout
     if (sq)
       launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, true, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1, notp);
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1, notp, h->g.ilo, h->g.ihi);
     else
       launch(h, kJacobiTB, k_jacobi_tb<T, V, TS, false, true>, dim3(blocks_for(h, ntt, R)), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1, notp);
+             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, h->d_courant + 1, notp, h->g.ilo, h->g.ihi);
   }
   template <int TS>
-  static void jacobi_tb(vof2d_ctx* h, int src, int dst, int adapt_par = -1) {
+  static void jacobi_tb(vof2d_ctx* h, int src, int dst, int adapt_par = -1, int first = 1, int last = 0) {
     const Consts<T> cc = C(h);
     const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;  // square cells: the product-carrying pipeline
     int ntt = 0;
     const int R = jacobi_tb_plan<TS, V>(h, sq, ntt);
-    jacobi_tb_launch<TS, V>(h, cc, sq, src, dst, R, ntt, adapt_par);
+    jacobi_tb_launch<TS, V>(h, cc, sq, src, dst, R, ntt, adapt_par, first, last);
   }
   template <bool STORED>
   static void correct(vof2d_ctx* h) {

@@ -172,6 +172,78 @@ void enqueue_step(vof2d_ctx* h, int64_t istep, bool lean = false, bool virt = fa
   if (lean) L<T>::template set_bc<BC_ALL>(h);   // :518, :525, :528 in one launch
 }
 
+// K steady-state steps of a full domain (the lean, virtual-ghost schedule of enqueue_step) with every kernel launched
+// twice: on rows [1, s] from the upper chain's stream and on rows [s + 1, nx] from the lower chain's.  The boundary s
+// moves UP by D rows from one kernel to the next, D >= the rows any kernel reads beyond the rows it produces (k_momentum
+// 3 + 1, k_jacobi_tb<5> 5, k_transport 3), so inside one batch
+//   * an upper launch reads only what upper launches before it produced (rows <= s_K + D <= s_(K-1)): the upper chain
+//     depends on nothing but itself;
+//   * a lower launch reads rows >= s_K + 1 - D: output of the previous kernel's lower AND upper launch -- one event;
+//   * nothing an upper launch writes (rows <= s_(K+1) <= s_K - D) is still to be read by a lower launch of an earlier
+//     kernel (rows >= s_K + 1 - D), and nothing a lower launch writes (rows > s_K) was or will be read by an upper one.
+// What it buys: the chip never drains between kernels -- the next kernel's upper half fills the tail of this kernel's
+// lower half, and kernels of different shapes (a Jacobi launch beside a transport launch) share the CUs.  Every row is
+// produced once, by the same arithmetic: the values do not change.  Both streams are in capture mode when this runs.
+constexpr int kHalvesDrift = 8;
+// Measured (tools/probes/halves_sweep.py, ms/step off -> on): 4096^2 fp64 dam-break 0.579 -> 0.560 (late) / 0.592 -> 0.562
+// (front), bubble 0.694 -> 0.622, 4096^2 fp32 0.367 -> 0.339, 8192^2 2.30 -> 2.24, 3072^2 0.353 -> 0.344, 2560^2 0.261 -> 0.251;
+// 2048^2 fp64 0.172 -> 0.190 and 1024^2 0.087 -> 0.097 (half launches too small to fill the chip): on from 6 M cells.
+inline bool halves_eligible(const vof2d_ctx* h, int K) {
+  const int nj = h->d.jacobi_iters / 5, total = K * (2 + nj);
+  const bool wanted = h->halves > 0 || (h->halves < 0 && (long)h->g.nx * h->g.ny >= 6000000L);
+  return wanted && h->stream2 && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 &&
+         h->d.jacobi_iters % 10 == 0 && h->g.nx / 2 - (total * kHalvesDrift + 1) / 2 >= 64;
+}
+template <typename T>
+bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
+  const int nj = h->d.jacobi_iters / 5, total = K * (2 + nj), nx = h->g.nx;
+  while ((int)h->hev.size() < total + K + 2) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    h->hev.push_back(e);
+  }
+  hipStream_t const top = h->stream, bot = h->stream2;
+  hipEvent_t* const ev_top = h->hev.data();            // [n]: the upper launch of kernel n has been enqueued behind ...
+  hipEvent_t* const ev_plan = h->hev.data() + total;   // [k]: the lower chain is through the Jacobi launches of step k
+  hipEvent_t const ev_fork = h->hev[total + K], ev_join = h->hev[total + K + 1];
+  bool ok = hipEventRecord(ev_fork, top) == hipSuccess && hipStreamWaitEvent(bot, ev_fork, 0) == hipSuccess;
+  int s = nx / 2 + (total * kHalvesDrift) / 2, n = 0;
+  hipEvent_t prev_top = nullptr;
+  auto both = [&](auto&& fn) {
+    fn(1, s, true);
+    ok = ok && hipEventRecord(ev_top[n], top) == hipSuccess;
+    if (prev_top) ok = ok && hipStreamWaitEvent(bot, prev_top, 0) == hipSuccess;
+    h->stream = bot;
+    fn(s + 1, nx, false);
+    h->stream = top;
+    prev_top = ev_top[n];
+    s -= kHalvesDrift;
+    ++n;
+  };
+  for (int k = 0; k < K && ok; ++k) {
+    const int64_t istep = first_step + k;
+    const int par = (int)(istep & 1);
+    // The upper launch of k_momentum carries the planner block of the step's Jacobi launches (tb_make_plan): it
+    // overwrites the plan the previous step's launches read and reads the hit masks they reported, so it waits
+    // for the lower chain to be through them -- the one edge from the lower chain to the upper.
+    if (k > 0) ok = ok && hipStreamWaitEvent(top, ev_plan[k - 1], 0) == hipSuccess;
+    both([&](int a, int b, bool upper) { L<T>::momentum(h, true, upper ? par : -1, a, b); });
+    int cur = fP, oth = fPT;
+    for (int j = 0; j < nj; ++j) {
+      both([&](int a, int b, bool) { L<T>::template jacobi_tb<5>(h, cur, oth, par, a, b); });
+      const int t = cur; cur = oth; oth = t;
+    }
+    ok = ok && hipEventRecord(ev_plan[k], bot) == hipSuccess;
+    both([&](int a, int b, bool) {
+      const RowRanges rr{{a, 1, 1}, {b, 0, 0}, {L<T>::transport_rows(h), 1, 1}};
+      if (istep % 2 == 0) L<T>::template transport<true>(h, &rr); else L<T>::template transport<false>(h, &rr);
+    });
+    swap_F(h);
+  }
+  ok = ok && hipEventRecord(ev_join, bot) == hipSuccess && hipStreamWaitEvent(top, ev_join, 0) == hipSuccess;
+  return ok;
+}
+
 int ensure_ok(vof2d_ctx* h) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -223,6 +295,7 @@ void destroy_graphs(vof2d_ctx* h) {
     for (int k = 0; k < 2; ++k)
       for (int o = 0; o < 2; ++o)
         if (h->gbatch[b][k][o]) { (void)hipGraphExecDestroy(h->gbatch[b][k][o]); h->gbatch[b][k][o] = nullptr; }
+  h->halves_captured[0] = h->halves_captured[1] = false;
   h->batching = true;   // (a parameter change may be what a capture tripped over: try again)
   for (int k = 0; k < 5; ++k)
     if (h->gphase[k]) { (void)hipGraphExecDestroy(h->gphase[k]); h->gphase[k] = nullptr; }

@@ -78,6 +78,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
       if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = VOF_EHIP; break; }
       h->own_stream = true;
     }
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { rc = VOF_EHIP; break; }   // the lower chain of enqueue_steps_halves
 #ifdef VOF_ARENA_EXP   // placement experiment (tools/probes/arena_modes.py): shift of the whole arena, extra bytes between fields
     const size_t shift_ = getenv("VOF2D_ARENA_SHIFT") ? (size_t)atoll(getenv("VOF2D_ARENA_SHIFT")) : 0;
     const size_t skew_ = getenv("VOF2D_FIELD_SKEW") ? (size_t)atoll(getenv("VOF2D_FIELD_SKEW")) : 0;
@@ -114,6 +115,8 @@ int vof_destroy(vof2d_handle h) {
   destroy_graphs(h);
   for (int k = 0; k < 2 * vof2d_ctx::kMaxTimed; ++k)
     if (h->tev[k]) (void)hipEventDestroy(h->tev[k]);
+  for (hipEvent_t e : h->hev) (void)hipEventDestroy(e);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   comm_teardown(h);
@@ -248,9 +251,15 @@ static void build_step_batches(vof2d_ctx* h) {
       if (slot) continue;
       hipGraph_t graph = nullptr;
       if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { ok = false; break; }
-      for (int k = 0; k < vof2d_ctx::kStepBatch[b]; ++k)
-        DISPATCH_T(h, enqueue_step<double>(h, first + k, true, true), enqueue_step<float>(h, first + k, true, true));
+      bool enq = true;
+      if (halves_eligible(h, h->step_batch[b])) {
+        h->halves_captured[b] = true;
+        DISPATCH_T(h, enq = enqueue_steps_halves<double>(h, first, h->step_batch[b]), enq = enqueue_steps_halves<float>(h, first, h->step_batch[b]));
+      } else
+        for (int k = 0; k < h->step_batch[b]; ++k)
+          DISPATCH_T(h, enqueue_step<double>(h, first + k, true, true), enqueue_step<float>(h, first + k, true, true));
       hipError_t e = hipStreamEndCapture(h->stream, &graph);          // (always: the stream must leave capture mode)
+      if (e == hipSuccess && !enq) e = hipErrorUnknown;
       if (e == hipSuccess) e = hipGraphInstantiate(&slot, graph, nullptr, nullptr, 0);
       if (graph) (void)hipGraphDestroy(graph);
       if (e != hipSuccess) { slot = nullptr; ok = false; break; }
@@ -298,11 +307,12 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       const int ori = h->fld[fF] == h->f_home ? 0 : 1;
       bool batched = false;
       for (int b = 0; b < vof2d_ctx::kStepBatches && !batched; ++b) {
-        const int K = vof2d_ctx::kStepBatch[b];
+        const int K = h->step_batch[b];
         if (nsteps - s < K || !h->gbatch[b][par][ori]) continue;
         HIPCHK(h, hipGraphLaunch(h->gbatch[b][par][ori], h->stream));
         h->istep += K - 1;
         s += K - 1;
+        if (h->halves_captured[b]) h->halves_steps += K;
         batched = true;
       }
       if (batched) {
@@ -608,10 +618,11 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
             : !strcmp(name, "momentum_rows") ? &h->mom_rows : !strcmp(name, "fctx_rows") ? &h->fctx_rows
             : !strcmp(name, "fctx_corr_rows") ? &h->fctx_corr_rows : !strcmp(name, "band_rows") ? &h->band_rows
             : !strcmp(name, "rows_per_wave") ? &h->rows_override : !strcmp(name, "fuse_transport") ? &h->fuse_transport
-            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : nullptr;
+            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : nullptr;
   if (knob) {
     *knob = (int)value;
     if (knob == &h->band_rows && *knob < 1) *knob = 1;
+    if (knob == &h->step_batch[0]) *knob = *knob < 4 ? 4 : (*knob & ~1);   // an even number of steps (see vof_step)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     destroy_graphs(h);
     return VOF_OK;
@@ -651,6 +662,10 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
     HIPCHK(h, hipMemcpyAsync(&v, h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64), sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *value = (int64_t)v;
+    return VOF_OK;
+  }
+  if (!strcmp(name, "halves_steps")) {   // steps replayed from batch graphs in the two-chain form (enqueue_steps_halves)
+    *value = h->halves_steps;
     return VOF_OK;
   }
   if (!strcmp(name, "exchange_graph_steps")) {  // steps vof_step_exchange replayed from a captured graph

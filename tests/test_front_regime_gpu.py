@@ -72,6 +72,7 @@ def test_plan_on_equals_plan_off_at_baseline_sizes(hip_api, n, steps, checks, dt
     on = engine(hip_api, n, n, "f64", "f32", ic=1, **kw)
     off = engine(hip_api, n, n, "f64", "f32", ic=1, **kw)
     off.set_param("jacobi_tb_adapt", 0)
+    off.set_param("overlap_halves", 0)               # (`on` also runs the two-chain batch graphs, the default at these sizes)
     active = 0
     for st in checks:
         while on.istep < st:
@@ -86,6 +87,7 @@ def test_plan_on_equals_plan_off_at_baseline_sizes(hip_api, n, steps, checks, dt
                 assert _tiny_cells(x) > 10000, "no tiny-value front at step %d" % st
             del x, y
     assert active >= len(checks) and off.get_counter("tb_plan_active") == 0
+    assert on.get_counter("halves_steps") >= steps - 20 and off.get_counter("halves_steps") == 0
     F = on.get("F")
     assert F.min() >= 0.0 and F.max() <= 1.0 and on.get_counter("courant_violations") == 0
 

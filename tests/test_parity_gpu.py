@@ -710,3 +710,42 @@ def test_buffer_stores_change_no_value(hip_api, dtype, ic, nx, ny):
     us, vs = a.get("u_star"), a.get("v_star")
     assert not us[1, :].any() and not us[nx + 1, :].any() and not vs[:, 1].any() and not vs[:, ny + 1].any()
     assert before == [c.get(f).tobytes() for c in (canary_lo, canary_hi) for f in STATE + ("u_star", "v_star", "rhs", "pt")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ic,nx,ny,ring", [("f64", 1, 640, 512, False), ("f32", 2, 512, 768, False), ("f64", 3, 448, 448, True),
+                                                  ("f32", 1, 400, 1100, True)])
+def test_overlap_halves_change_no_value(hip_api, oracle_api, dtype, ic, nx, ny, ring):
+    """The batch graphs in the two-chain form (enqueue_steps_halves: every kernel of a step as two launches on the rows
+    above and below a boundary that moves up from kernel to kernel, the lower chain one kernel behind the upper;
+    default from 6 M cells, forced here) against the one-chain form and the oracle: every row is produced once, by the
+    same arithmetic.  `ring`: a band of tiny pressure values, so that the launches of both chains run the equal-cost
+    work plan (one plan per step, made by the upper k_momentum launch, clipped by each launch to its rows)."""
+    kw = {"gy": 0.0} if ring else {}
+    a = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
+    a.set_param("overlap_halves", 1)
+    b = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
+    b.set_param("overlap_halves", 0)
+    o = engine(oracle_api, nx, ny, dtype, "f32", ic=ic, **kw)
+    if ring:
+        tiny = 1e-290 if dtype == "f64" else 1e-32
+        rng = np.random.default_rng(nx + ny)
+        p0 = np.zeros((nx + 2, ny + 2))
+        i, j = np.meshgrid(np.arange(nx + 2), np.arange(ny + 2), indexing="ij")
+        r = np.hypot(i - 0.5 * nx, j - 0.4 * ny)          # (the ring crosses the boundary between the chains, near nx / 2)
+        band = (r > 0.2 * min(nx, ny)) & (r < 0.4 * min(nx, ny))
+        p0[band] = tiny * rng.uniform(0.5, 2.0, size=int(band.sum()))
+        p0[r <= 0.2 * min(nx, ny)] = 1.0
+        for e in (a, b, o):
+            e.set("p", p0)
+    planned = 0
+    for st in (1, 11, 12, 22, 23, 40):       # 1 eager step; 8 + 2 from batches; 1 from the single-step graph; 8 + 2; 1; 8 + 8 + 1
+        for e in (a, b, o):
+            e.step(st - e.istep)
+        planned += a.get_counter("tb_plan_active")
+        assert_fields_same(a, b, STATE + ("u_star", "v_star", "rhs"), ctx="halves on / off, %s %dx%d step %d" % (dtype, nx, ny, st))
+        assert_fields_same(a, o, ctx="halves on / oracle, %s %dx%d step %d" % (dtype, nx, ny, st))
+    assert a.get_counter("halves_steps") == 36 and b.get_counter("halves_steps") == 0
+    assert a.get_counter("courant_violations") == o.get_counter("courant_violations")
+    if ring:
+        assert planned >= 2, planned

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -131,6 +132,14 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<Cfg> cfgs;
+  const bool mall = argc > 2 && !strcmp(argv[2], "mall");   // the same shapes on bands of rows small enough to stay in the 256 MB MALL between launches
+  if (mall) {
+    for (int nxo : {4096, 1024, 512, 256})
+      for (int R : {2, 4, 16}) {
+        cfgs.push_back({4, 3, R, R == 16 ? 6 : 0, 3, 0, 1, 0, 4, 0, nxo, 0, 0, 128, 0, 63});
+        cfgs.push_back({2, 1, R, R == 16 ? 10 : 0, 3, 0, 1, 0, 4, 0, nxo, 0, 0, 128, 0, 63});
+      }
+  } else
   for (int R : {2, 51})
     for (int L : {0, 10}) {
       if (R == 2 && L) continue;
@@ -140,8 +149,8 @@ int main(int argc, char** argv) {
       cfgs.push_back({2, 1, R, L, 3, 0, 1, 0, 4, 0, 0, 0, 0, 112, 4, 59});    // 112 = 7 x 128 B
       cfgs.push_back({2, 1, R, L, 3, 0, 1, 0, 4, 0, 0, 0, 0, 96, 8, 55});     // 96 = 6 x 128 B
     }
-  for (int ts : {128, 120, 112}) cfgs.push_back({4, 3, 16, 6, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
-  for (int ts : {128, 124, 112}) cfgs.push_back({3, 3, 14, 7, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
+  if (!mall) for (int ts : {128, 120, 112}) cfgs.push_back({4, 3, 16, 6, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
+  if (!mall) for (int ts : {128, 124, 112}) cfgs.push_back({3, 3, 14, 7, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
   for (const Cfg& c : cfgs) {
     const int nxr = c.nxo ? c.nxo : nx;
     a.nx = nxr; a.wpb = c.wpb; a.sync_rows = c.sync; a.work = c.work; a.stagger = c.stagger; a.tstride = c.tstride; a.vlo = c.vlo; a.vhi = c.vhi; a.ntiles = (ny + c.tstride - 1) / c.tstride; a.km = 0.999999; a.ka = 1e-9;
