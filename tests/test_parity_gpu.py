@@ -749,3 +749,27 @@ def test_overlap_halves_change_no_value(hip_api, oracle_api, dtype, ic, nx, ny, 
     assert a.get_counter("courant_violations") == o.get_counter("courant_violations")
     if ring:
         assert planned >= 2, planned
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,nx,ny", [("f64", 448, 400), ("f32", 400, 300)])
+def test_warm_handle_reset_to_the_initial_state_repeats_the_run(hip_api, dtype, nx, ny):
+    """bench.py's sustained leg warms its handle (the step graphs are captured once per handle), then puts the initial
+    state back: F = u = v = p = 0, set_init_F (which, like 2dvof.py:141-147, only writes the liquid cells of the dam),
+    istep = 0.  From there the handle must repeat a new handle's run value for
+    value -- nothing else a run depends on survives in the handle (the scratch fields are rewritten before they are
+    read; the work plan and its masks only decide which wave takes which rows)."""
+    fresh = engine(hip_api, nx, ny, dtype, "f32", ic=1)
+    warm = engine(hip_api, nx, ny, dtype, "f32", ic=1)
+    warm.set_param("overlap_halves", 1)
+    warm.step(13)
+    zeros = np.zeros((nx + 2, ny + 2))
+    for f in ("F", "u", "v", "p"):
+        warm.set(f, zeros)
+    warm.set_init_F(1)
+    warm.istep = 0
+    for st in (1, 14, 40):
+        fresh.step(st - fresh.istep)
+        warm.step(st - warm.istep)
+        assert_fields_same(warm, fresh, ctx="%s step %d" % (dtype, st))
+    assert warm.get_counter("halves_steps") > 20
