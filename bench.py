@@ -440,7 +440,8 @@ def roofline_record(step_kernels, traffic, traffic_note, nprof, prof_note, sweep
     second engine did not fit) the back-to-back figure of vof_time_jacobi stands in and says so."""
     k = step_kernels.get("k_jacobi_tb")
     if k:
-        us, src = k["us_per_launch_dispatch"], "in-situ profile, %d steps from step 11 of a fresh run" % nprof
+        us, src = k["us_per_launch_dispatch"], ("in-situ profile (vof_profile_steps: the four launches of a step on the whole grid, one at a time, "
+                                                "HIP events around each), %d steps from step 11 of a fresh run" % nprof)
     else:
         us, src = fused["us_per_launch_back_to_back"], "back-to-back launches (vof_time_jacobi): %s" % (prof_note or "no in-situ profile on this path")
     achieved = sweep_bytes / (us * 1e-6) / 1e9
@@ -743,7 +744,11 @@ def main():
                 "exchange_graph_steps_in_timed_region": graph_steps,
                 "multi_gpu_hardware_verified": False if world > 1 else None,
                 "arrays_per_cell_update": ARRAYS_PER_STEP,
-                "bytes_per_cell_update_algorithmic": ARRAYS_PER_STEP * esz},
+                "bytes_per_cell_update_algorithmic": ARRAYS_PER_STEP * esz,
+                # two-chain: every kernel of a step as two launches (rows above / below a moving boundary) on two
+                # streams, the lower chain one kernel behind the upper; one-chain: four launches per
+                # step, one after the other (small grids, strips, VOF2D_OVERLAP_HALVES=0)
+                "step_schedule": ("two-chain batch graphs" if eng.get_param("overlap_halves") else "one-chain batch graphs") if not dist_path else "strips"},
             # `roofline` = the Poisson Jacobi kernel THE STEP RUNS, k_jacobi_tb (five sweeps per launch): algorithmic bytes =
             # 3 arrays x sizeof(T) x cells per launch (read p, read rhs, write p after five sweeps; SURVEY 8d's 24 B rule
             # per launch), duration = its average dispatch over the in-situ profile above (HIP events on the launch

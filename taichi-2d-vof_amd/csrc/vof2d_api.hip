@@ -79,6 +79,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
       h->own_stream = true;
     }
     if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { rc = VOF_EHIP; break; }   // the lower chain of enqueue_steps_halves
+    if (const char* ev = getenv("VOF2D_OVERLAP_HALVES")) h->halves = atoi(ev);   // (profiling runs: per-kernel counters want one kernel at a time)
 #ifdef VOF_ARENA_EXP   // placement experiment (tools/probes/arena_modes.py): shift of the whole arena, extra bytes between fields
     const size_t shift_ = getenv("VOF2D_ARENA_SHIFT") ? (size_t)atoll(getenv("VOF2D_ARENA_SHIFT")) : 0;
     const size_t skew_ = getenv("VOF2D_FIELD_SKEW") ? (size_t)atoll(getenv("VOF2D_FIELD_SKEW")) : 0;
@@ -642,6 +643,7 @@ int vof_get_param(vof2d_handle h, const char* name, double* value) {
   if (!strcmp(name, "rows_per_wave")) { *value = (double)pick_rows(h, h->g.ntj); return VOF_OK; }
   if (!strcmp(name, "jacobi_tb")) { *value = (double)h->tb; return VOF_OK; }
   if (!strcmp(name, "jacobi_tb_adapt")) { *value = (double)h->tb_adapt; return VOF_OK; }
+  if (!strcmp(name, "overlap_halves")) { *value = halves_eligible(h, h->step_batch[0]) ? 1.0 : 0.0; return VOF_OK; }   // effective
   if (!strcmp(name, "fuse_transport")) {  // 1 if vof_step runs both FCT sweeps as one kernel on this handle
     *value = (h->g.wall_lo && h->g.wall_hi && h->fuse_transport) ? 1.0 : 0.0;
     return VOF_OK;
