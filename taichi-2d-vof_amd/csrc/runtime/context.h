@@ -169,7 +169,7 @@ struct vof2d_ctx {
   // boundary that moves up by kHalvesDrift rows from kernel to kernel, the upper chain on `stream`, the lower on
   // `stream2`; a lower launch waits for the upper launch of the kernel before it only (enqueue_steps_halves)
   int halves = -1;   // -1: where it pays (halves_eligible), 0: never, 1: wherever the schedule allows
-  hipStream_t stream2 = nullptr;
+  std::vector<hipStream_t> chain_streams;   // streams of the chains below the first
   bool halves_captured[2] = {false, false};   // the batch graphs of size step_batch[b] the handle holds were captured in this form
   int64_t halves_steps = 0;       // steps replayed from them (counter "halves_steps")
   std::vector<hipEvent_t> hev;

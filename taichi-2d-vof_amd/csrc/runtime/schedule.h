@@ -188,59 +188,81 @@ constexpr int kHalvesDrift = 8;
 // Measured (tools/probes/halves_sweep.py, ms/step off -> on): 4096^2 fp64 dam-break 0.579 -> 0.560 (late) / 0.592 -> 0.562
 // (front), bubble 0.694 -> 0.622, 4096^2 fp32 0.367 -> 0.339, 8192^2 2.30 -> 2.24, 3072^2 0.353 -> 0.344, 2560^2 0.261 -> 0.251;
 // 2048^2 fp64 0.172 -> 0.190 and 1024^2 0.087 -> 0.097 (half launches too small to fill the chip): on from 6 M cells.
+// chains: two; three from 32 M cells (8192^2: 2.30 ms/step in one chain, 2.29 in two, 2.16 in three, 2.17 in four; 4096^2: 0.595 / 0.574 /
+// 0.566 / 0.579 inside the front, 0.582 / 0.562 / 0.565 / 0.583 behind it); knob values >= 2 force a count
+inline int halves_chains(const vof2d_ctx* h) {
+  if (h->halves >= 2) return h->halves > 8 ? 8 : h->halves;
+  return (long)h->g.nx * h->g.ny >= 32000000L ? 3 : 2;
+}
 inline bool halves_eligible(const vof2d_ctx* h, int K) {
   const int nj = h->d.jacobi_iters / 5, total = K * (2 + nj);
   const bool wanted = h->halves > 0 || (h->halves < 0 && (long)h->g.nx * h->g.ny >= 6000000L);
-  return wanted && h->stream2 && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 &&
-         h->d.jacobi_iters % 10 == 0 && h->g.nx / 2 - (total * kHalvesDrift + 1) / 2 >= 64;
+  return wanted && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 &&
+         h->d.jacobi_iters % 10 == 0 && h->g.nx / halves_chains(h) - (total * kHalvesDrift + 1) / 2 >= 64;
 }
-template <typename T>
-bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
-  const int nj = h->d.jacobi_iters / 5, total = K * (2 + nj), nx = h->g.nx;
-  while ((int)h->hev.size() < total + K + 2) {
+// (called outside capture mode: streams and events the capture will need)
+inline bool halves_prepare(vof2d_ctx* h, int K) {
+  const int P = halves_chains(h), nj = h->d.jacobi_iters / 5, total = K * (2 + nj);
+  while ((int)h->chain_streams.size() < P - 1) {
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+    h->chain_streams.push_back(st);
+  }
+  while ((int)h->hev.size() < (P - 1) * total + K + 1 + (P - 1)) {
     hipEvent_t e = nullptr;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
     h->hev.push_back(e);
   }
-  hipStream_t const top = h->stream, bot = h->stream2;
-  hipEvent_t* const ev_top = h->hev.data();            // [n]: the upper launch of kernel n has been enqueued behind ...
-  hipEvent_t* const ev_plan = h->hev.data() + total;   // [k]: the lower chain is through the Jacobi launches of step k
-  hipEvent_t const ev_fork = h->hev[total + K], ev_join = h->hev[total + K + 1];
-  bool ok = hipEventRecord(ev_fork, top) == hipSuccess && hipStreamWaitEvent(bot, ev_fork, 0) == hipSuccess;
-  int s = nx / 2 + (total * kHalvesDrift) / 2, n = 0;
-  hipEvent_t prev_top = nullptr;
-  auto both = [&](auto&& fn) {
-    fn(1, s, true);
-    ok = ok && hipEventRecord(ev_top[n], top) == hipSuccess;
-    if (prev_top) ok = ok && hipStreamWaitEvent(bot, prev_top, 0) == hipSuccess;
-    h->stream = bot;
-    fn(s + 1, nx, false);
-    h->stream = top;
-    prev_top = ev_top[n];
-    s -= kHalvesDrift;
+  return true;
+}
+template <typename T>
+bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
+  const int P = halves_chains(h), nj = h->d.jacobi_iters / 5, total = K * (2 + nj), nx = h->g.nx;
+  hipStream_t st[8];
+  st[0] = h->stream;
+  for (int p = 1; p < P; ++p) st[p] = h->chain_streams[p - 1];
+  hipEvent_t* const ev_done = h->hev.data();                        // [p * total + n]: launch n of chain p (p < P - 1) is enqueued behind ...
+  hipEvent_t* const ev_plan = h->hev.data() + (P - 1) * total;      // [k]: the last chain is through the Jacobi launches of step k
+  hipEvent_t const ev_fork = h->hev[(P - 1) * total + K];
+  hipEvent_t* const ev_join = h->hev.data() + (P - 1) * total + K + 1;   // [p - 1]
+  bool ok = hipEventRecord(ev_fork, st[0]) == hipSuccess;
+  for (int p = 1; p < P; ++p) ok = ok && hipStreamWaitEvent(st[p], ev_fork, 0) == hipSuccess;
+  int s[8];                                                         // chain p produces rows (s[p - 1], s[p]]
+  for (int p = 0; p < P - 1; ++p) s[p] = (int)((long)(p + 1) * nx / P) + (total * kHalvesDrift) / 2;
+  int n = 0;
+  auto all = [&](auto&& fn) {
+    for (int p = 0; p < P; ++p) {
+      if (p > 0 && n > 0) ok = ok && hipStreamWaitEvent(st[p], ev_done[(p - 1) * total + n - 1], 0) == hipSuccess;
+      h->stream = st[p];
+      fn(p == 0 ? 1 : s[p - 1] + 1, p == P - 1 ? nx : s[p], p == 0);
+      if (p < P - 1) ok = ok && hipEventRecord(ev_done[p * total + n], st[p]) == hipSuccess;
+    }
+    h->stream = st[0];
+    for (int p = 0; p < P - 1; ++p) s[p] -= kHalvesDrift;
     ++n;
   };
   for (int k = 0; k < K && ok; ++k) {
     const int64_t istep = first_step + k;
     const int par = (int)(istep & 1);
-    // The upper launch of k_momentum carries the planner block of the step's Jacobi launches (tb_make_plan): it
-    // overwrites the plan the previous step's launches read and reads the hit masks they reported, so it waits
-    // for the lower chain to be through them -- the one edge from the lower chain to the upper.
-    if (k > 0) ok = ok && hipStreamWaitEvent(top, ev_plan[k - 1], 0) == hipSuccess;
-    both([&](int a, int b, bool upper) { L<T>::momentum(h, true, upper ? par : -1, a, b); });
+    // The first chain's launch of k_momentum carries the planner block of the step's Jacobi launches (tb_make_plan):
+    // it overwrites the plan the previous step's launches read and reads the hit masks they reported, so it waits
+    // for the last chain to be through them -- the one edge that points up the chains.
+    if (k > 0) ok = ok && hipStreamWaitEvent(st[0], ev_plan[k - 1], 0) == hipSuccess;
+    all([&](int a, int b, bool first) { L<T>::momentum(h, true, first ? par : -1, a, b); });
     int cur = fP, oth = fPT;
     for (int j = 0; j < nj; ++j) {
-      both([&](int a, int b, bool) { L<T>::template jacobi_tb<5>(h, cur, oth, par, a, b); });
+      all([&](int a, int b, bool) { L<T>::template jacobi_tb<5>(h, cur, oth, par, a, b); });
       const int t = cur; cur = oth; oth = t;
     }
-    ok = ok && hipEventRecord(ev_plan[k], bot) == hipSuccess;
-    both([&](int a, int b, bool) {
+    ok = ok && hipEventRecord(ev_plan[k], st[P - 1]) == hipSuccess;
+    all([&](int a, int b, bool) {
       const RowRanges rr{{a, 1, 1}, {b, 0, 0}, {L<T>::transport_rows(h), 1, 1}};
       if (istep % 2 == 0) L<T>::template transport<true>(h, &rr); else L<T>::template transport<false>(h, &rr);
     });
     swap_F(h);
   }
-  ok = ok && hipEventRecord(ev_join, bot) == hipSuccess && hipStreamWaitEvent(top, ev_join, 0) == hipSuccess;
+  for (int p = 1; p < P; ++p)
+    ok = ok && hipEventRecord(ev_join[p - 1], st[p]) == hipSuccess && hipStreamWaitEvent(st[0], ev_join[p - 1], 0) == hipSuccess;
   return ok;
 }
 

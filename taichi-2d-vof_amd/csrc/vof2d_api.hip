@@ -78,7 +78,6 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
       if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = VOF_EHIP; break; }
       h->own_stream = true;
     }
-    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { rc = VOF_EHIP; break; }   // the lower chain of enqueue_steps_halves
     if (const char* ev = getenv("VOF2D_OVERLAP_HALVES")) h->halves = atoi(ev);   // (profiling runs: per-kernel counters want one kernel at a time)
 #ifdef VOF_ARENA_EXP   // placement experiment (tools/probes/arena_modes.py): shift of the whole arena, extra bytes between fields
     const size_t shift_ = getenv("VOF2D_ARENA_SHIFT") ? (size_t)atoll(getenv("VOF2D_ARENA_SHIFT")) : 0;
@@ -117,7 +116,7 @@ int vof_destroy(vof2d_handle h) {
   for (int k = 0; k < 2 * vof2d_ctx::kMaxTimed; ++k)
     if (h->tev[k]) (void)hipEventDestroy(h->tev[k]);
   for (hipEvent_t e : h->hev) (void)hipEventDestroy(e);
-  if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  for (hipStream_t st : h->chain_streams) (void)hipStreamDestroy(st);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   comm_teardown(h);
@@ -251,9 +250,10 @@ static void build_step_batches(vof2d_ctx* h) {
       hipGraphExec_t& slot = h->gbatch[b][(int)(first & 1)][ori_c];
       if (slot) continue;
       hipGraph_t graph = nullptr;
+      const bool chains = halves_eligible(h, h->step_batch[b]) && halves_prepare(h, h->step_batch[b]);
       if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { ok = false; break; }
       bool enq = true;
-      if (halves_eligible(h, h->step_batch[b])) {
+      if (chains) {
         h->halves_captured[b] = true;
         DISPATCH_T(h, enq = enqueue_steps_halves<double>(h, first, h->step_batch[b]), enq = enqueue_steps_halves<float>(h, first, h->step_batch[b]));
       } else
