@@ -187,16 +187,18 @@ void enqueue_step(vof2d_ctx* h, int64_t istep, bool lean = false, bool virt = fa
 constexpr int kHalvesDrift = 8;
 // Measured (tools/probes/halves_sweep.py, ms/step off -> on): 4096^2 fp64 dam-break 0.579 -> 0.560 (late) / 0.592 -> 0.562
 // (front), bubble 0.694 -> 0.622, 4096^2 fp32 0.367 -> 0.339, 8192^2 2.30 -> 2.24, 3072^2 0.353 -> 0.344, 2560^2 0.261 -> 0.251;
-// 2048^2 fp64 0.172 -> 0.190 and 1024^2 0.087 -> 0.097 (half launches too small to fill the chip): on from 6 M cells.
+// 2048^2 fp64 0.172 -> 0.190 and 1024^2 0.087 -> 0.097 (half launches too small to fill the chip): on from 6 M cells and 1024 rows per chain.
 // chains: two; three from 32 M cells (8192^2: 2.30 ms/step in one chain, 2.29 in two, 2.16 in three, 2.17 in four; 4096^2: 0.595 / 0.574 /
 // 0.566 / 0.579 inside the front, 0.582 / 0.562 / 0.565 / 0.583 behind it); knob values >= 2 force a count
 inline int halves_chains(const vof2d_ctx* h) {
   if (h->halves >= 2) return h->halves > 8 ? 8 : h->halves;
-  return (long)h->g.nx * h->g.ny >= 32000000L ? 3 : 2;
+  return (long)h->g.nx * h->g.ny >= 32000000L && h->g.nx >= 3 * 1024 ? 3 : 2;
 }
 inline bool halves_eligible(const vof2d_ctx* h, int K) {
   const int nj = h->d.jacobi_iters / 5, total = K * (2 + nj);
-  const bool wanted = h->halves > 0 || (h->halves < 0 && (long)h->g.nx * h->g.ny >= 6000000L);
+  // (a chain of few rows is short chunks and little else: 1024 x 8192 in two chains of 512 rows 0.319 -> 0.334 ms/step,
+  // 2048 x 8192 0.583 -> 0.562, 8192 x 2048 0.604 -> 0.593)
+  const bool wanted = h->halves > 0 || (h->halves < 0 && (long)h->g.nx * h->g.ny >= 6000000L && h->g.nx >= 2 * 1024);
   return wanted && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 &&
          h->d.jacobi_iters % 10 == 0 && h->g.nx / halves_chains(h) - (total * kHalvesDrift + 1) / 2 >= 64;
 }

@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 ap = argparse.ArgumentParser()
 ap.add_argument("settings", nargs="+")
 ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--ny", type=int, default=0)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("-ic", type=int, default=1)
 ap.add_argument("--skip", type=int, default=60)
@@ -22,7 +23,7 @@ api = hip_api()
 engs = []
 for k in range(a.engines):
     for st in a.settings:
-        e = Engine(api, make_desc(api, a.n, a.n, a.dtype, "f32", device=0, **({"dt": a.dt} if a.dt > 0 else {})))
+        e = Engine(api, make_desc(api, a.n, a.ny or a.n, a.dtype, "f32", device=0, **({"dt": a.dt} if a.dt > 0 else {})))
         for kv in st.split(","):
             if kv:
                 name, v = kv.split("=")
