@@ -95,6 +95,15 @@ __global__ __launch_bounds__(1024) void k_stream(Args a) {
     return;
   }
   const unsigned total = (unsigned)a.nchunks * (unsigned)a.ntiles;
+  if (a.persistent == 2) {   // static stride: wave w takes items w, w + W, w + 2 W, ... (no queue)
+    const unsigned nw = gridDim.x * a.wpb;
+    for (unsigned item = blockIdx.x * a.wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); item < total; item += nw) {
+      const int tj = item % a.ntiles, ch = item / a.ntiles;
+      const int ra = ch * a.R, rb = min(ra + a.R - 1, a.nx - 1);
+      chunk<NIN, NOUT, D>(a, tj, ra, rb, lane);
+    }
+    return;
+  }
   for (;;) {
     unsigned item = 0;
     if (lane == 0) item = atomicAdd(a.queue, 1u);
@@ -132,6 +141,20 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<Cfg> cfgs;
+  const bool stat = argc > 2 && !strcmp(argv[2], "static");   // persistent waves with a static stride against one wave per chunk
+  if (stat) {
+    for (int rep = 0; rep < 2; ++rep)
+      for (int R : {16, 14, 8}) {
+        const int L = 6;
+        cfgs.push_back({4, 3, R, L, 3, 0, 1, 0, 4, 0, 0, 0, 0, 128, 0, 63});
+        cfgs.push_back({4, 3, R, L, 3, 2, 1, 0, 4, 0, 0, 0, 0, 128, 0, 63});
+        cfgs.push_back({4, 3, R, L, 3, 1, 1, 0, 4, 0, 0, 0, 0, 128, 0, 63});
+        cfgs.push_back({3, 3, R, 7, 3, 0, 1, 0, 4, 0, 0, 0, 0, 128, 0, 63});
+        cfgs.push_back({3, 3, R, 7, 3, 2, 1, 0, 4, 0, 0, 0, 0, 128, 0, 63});
+        cfgs.push_back({4, 3, R, L, 3, 0, 1, 0, 4, 0, 0, 60, 0, 128, 0, 63});
+        cfgs.push_back({4, 3, R, L, 3, 2, 1, 0, 4, 0, 0, 60, 0, 128, 0, 63});
+      }
+  }
   const bool mall = argc > 2 && !strcmp(argv[2], "mall");   // the same shapes on bands of rows small enough to stay in the 256 MB MALL between launches
   if (mall) {
     for (int nxo : {4096, 1024, 512, 256})
@@ -139,7 +162,7 @@ int main(int argc, char** argv) {
         cfgs.push_back({4, 3, R, R == 16 ? 6 : 0, 3, 0, 1, 0, 4, 0, nxo, 0, 0, 128, 0, 63});
         cfgs.push_back({2, 1, R, R == 16 ? 10 : 0, 3, 0, 1, 0, 4, 0, nxo, 0, 0, 128, 0, 63});
       }
-  } else
+  } else if (!stat)
   for (int R : {2, 51})
     for (int L : {0, 10}) {
       if (R == 2 && L) continue;
@@ -149,8 +172,8 @@ int main(int argc, char** argv) {
       cfgs.push_back({2, 1, R, L, 3, 0, 1, 0, 4, 0, 0, 0, 0, 112, 4, 59});    // 112 = 7 x 128 B
       cfgs.push_back({2, 1, R, L, 3, 0, 1, 0, 4, 0, 0, 0, 0, 96, 8, 55});     // 96 = 6 x 128 B
     }
-  if (!mall) for (int ts : {128, 120, 112}) cfgs.push_back({4, 3, 16, 6, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
-  if (!mall) for (int ts : {128, 124, 112}) cfgs.push_back({3, 3, 14, 7, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
+  if (!mall && !stat) for (int ts : {128, 120, 112}) cfgs.push_back({4, 3, 16, 6, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
+  if (!mall && !stat) for (int ts : {128, 124, 112}) cfgs.push_back({3, 3, 14, 7, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
   for (const Cfg& c : cfgs) {
     const int nxr = c.nxo ? c.nxo : nx;
     a.nx = nxr; a.wpb = c.wpb; a.sync_rows = c.sync; a.work = c.work; a.stagger = c.stagger; a.tstride = c.tstride; a.vlo = c.vlo; a.vhi = c.vhi; a.ntiles = (ny + c.tstride - 1) / c.tstride; a.km = 0.999999; a.ka = 1e-9;
@@ -182,7 +205,7 @@ int main(int argc, char** argv) {
     const double alg = (double)(c.nin + c.nout) * nxr * ny * 8.0;
     const double req = ((double)c.nin * (c.R + c.L) / c.R + c.nout) * nxr * ny * 8.0;
     printf("tile stride %3d lanes %d-%d | stagger %2d work %3d | nx %d wpb %2d sync %d | in %d out %d R %2d L %2d waves/SIMD %d %s D %d %s: %7.1f us  alg %.2f TB/s  requested %.2f TB/s  (%ld waves%s)\n", c.tstride, c.vlo, c.vhi, c.stagger, c.work, nxr, c.wpb, c.sync, c.nin, c.nout, c.R, c.L,
-           c.wps, c.persistent ? "queue" : "grid ", c.D, c.nt ? "nt-loads" : "        ", us, alg / us * 1e-6, req / us * 1e-6, waves,
+           c.wps, c.persistent == 2 ? "static" : c.persistent ? "queue" : "grid ", c.D, c.nt ? "nt-loads" : "        ", us, alg / us * 1e-6, req / us * 1e-6, waves,
            hipGetLastError() == hipSuccess ? "" : " ERROR");
     fflush(stdout);
   }
