@@ -28,7 +28,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_jacobi_tb"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["algorithmic_bytes_per_launch"] == 3 * 8 * 512 * 512 and rf["sweeps_per_launch"] == 5
-    assert "traffic" in rf and isinstance(rf["traffic_note"], str) and "in-situ profile, 14 steps" in rf["duration_source"]
+    assert "traffic" in rf and isinstance(rf["traffic_note"], str) and rf["duration_source"].startswith("in-situ profile") and "14 steps" in rf["duration_source"]
+    assert d["config"]["step_schedule"] == "one-chain batch graphs"          # (512^2: chains start at 6 M cells)
     assert abs(rf["us_per_launch"] - d["step_kernels"]["k_jacobi_tb"]["us_per_launch_dispatch"]) < 1e-9
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"]
     one = rf["north_star_single_sweep"]            # the single-sweep kernel of the north star's wording: a sub-record
