@@ -246,10 +246,12 @@ struct L {
     // where the plan counted on three, which breaks the round structure of a multi-round launch (8192^2 on one GPU:
     // 397 -> 435 us)
     const bool one_round = (long)blocks_for(h, ntt, R) * 4 <= resident_waves(h, k_jacobi_tb<T, VV, TS, true, false>);
-    if (sq && one_round && buffer_stores_ok(h) && (h->buf_stores & 2))
-      launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false, true>, dim3(nblk), 0, h->g, cc,
-             (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp, first, last);
-    else if (sq)
+    constexpr bool kBufForm = sizeof(T) * VV == 16 || sizeof(T) * VV == 8;   // (store_buf_nt: one b128 / b64 store per lane)
+    if (kBufForm && sq && one_round && buffer_stores_ok(h) && (h->buf_stores & 2)) {
+      if constexpr (kBufForm)
+        launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false, true>, dim3(nblk), 0, h->g, cc,
+               (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp, first, last);
+    } else if (sq)
       launch(h, kJacobiTB, k_jacobi_tb<T, VV, TS, true, false>, dim3(nblk), 0, h->g, cc,
              (const T*)F_<T>(h, src), (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, none, tp, first, last);
     else
@@ -282,6 +284,13 @@ struct L {
     const Consts<T> cc = C(h);
     const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;  // square cells: the product-carrying pipeline
     int ntt = 0;
+#ifdef VOF_TB_VV      // EXPERIMENT: wider tiles for the fused Jacobi kernel
+    if (TS == 5 && sizeof(T) == 8) {
+      const int R = jacobi_tb_plan<TS, VOF_TB_VV>(h, sq, ntt);
+      jacobi_tb_launch<TS, VOF_TB_VV>(h, cc, sq, src, dst, R, ntt, -1, first, last);
+      return;
+    }
+#endif
     const int R = jacobi_tb_plan<TS, V>(h, sq, ntt);
     jacobi_tb_launch<TS, V>(h, cc, sq, src, dst, R, ntt, adapt_par, first, last);
   }
