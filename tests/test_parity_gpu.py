@@ -713,9 +713,9 @@ def test_buffer_stores_change_no_value(hip_api, dtype, ic, nx, ny):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,ic,nx,ny,ring", [("f64", 1, 640, 512, False), ("f32", 2, 512, 768, False), ("f64", 3, 448, 448, True),
-                                                  ("f32", 1, 400, 1100, True)])
-def test_overlap_halves_change_no_value(hip_api, oracle_api, dtype, ic, nx, ny, ring):
+@pytest.mark.parametrize("dtype,ic,nx,ny,ring,chains", [("f64", 1, 640, 512, False, 2), ("f32", 2, 512, 768, False, 2), ("f64", 3, 448, 448, True, 2),
+                                                         ("f32", 1, 400, 1100, True, 2), ("f64", 1, 700, 333, True, 3), ("f32", 3, 900, 250, False, 4)])
+def test_overlap_halves_change_no_value(hip_api, oracle_api, dtype, ic, nx, ny, ring, chains):
     """The batch graphs in the two-chain form (enqueue_steps_halves: every kernel of a step as two launches on the rows
     above and below a boundary that moves up from kernel to kernel, the lower chain one kernel behind the upper;
     default from 6 M cells, forced here) against the one-chain form and the oracle: every row is produced once, by the
@@ -723,7 +723,7 @@ def test_overlap_halves_change_no_value(hip_api, oracle_api, dtype, ic, nx, ny, 
     work plan (one plan per step, made by the upper k_momentum launch, clipped by each launch to its rows)."""
     kw = {"gy": 0.0} if ring else {}
     a = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
-    a.set_param("overlap_halves", 1)
+    a.set_param("overlap_halves", chains)         # (odd ny: the exec-masked store forms; 3 / 4 chains: every middle chain has two moving boundaries)
     b = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
     b.set_param("overlap_halves", 0)
     o = engine(oracle_api, nx, ny, dtype, "f32", ic=ic, **kw)
