@@ -124,7 +124,15 @@ __device__ __forceinline__ T* wave_uniform(T* p) {
 template <typename T, int V>
 __device__ __forceinline__ void store_buf_nt(const T* base, int lane_off_bytes, int row_off_bytes, const T (&c)[V]) {
   static_assert(sizeof(T) * V == 16 || sizeof(T) * V == 8, "one b128 / b64 store per lane");
+  // The row offset travels in the lane offsets (kBufSkip + a row offset still lies outside the window), not in the
+  // instruction's scalar offset: with an SGPR soffset the compiler assumes that the VGPRs holding more than 8 bytes
+  // of store data may be overwritten by the very next VALU instruction, and on gfx950 they may not -- k_tm's rhs
+  // store picked up, in some lanes and not every time, the v* values a v_mov wrote into its data registers one
+  // instruction later.  With soffset = 0 the hazard recognizer inserts the wait state itself.
   row_off_bytes = __builtin_amdgcn_readfirstlane(row_off_bytes);
+  lane_off_bytes += row_off_bytes;
+  asm volatile("" : "+v"(lane_off_bytes));   // (or the instruction selection splits the uniform part off into soffset again)
+  row_off_bytes = 0;
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(wave_uniform(const_cast<T*>(base)), 0, kBufSkip, 0x00020000);
   typedef T vec_t __attribute__((ext_vector_type(V)));
   vec_t k;

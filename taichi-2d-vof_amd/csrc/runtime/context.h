@@ -168,6 +168,9 @@ struct vof2d_ctx {
   // knob "overlap_halves": the batch graphs run every kernel of a step as two launches, on the rows above and below a
   // boundary that moves up by kHalvesDrift rows from kernel to kernel, the upper chain on `stream`, the lower on
   // `stream2`; a lower launch waits for the upper launch of the kernel before it only (enqueue_steps_halves)
+  int fuse_tm = 0;          // knob: batch graphs run k_transport + the next step's k_momentum as one kernel (k_tm)
+  int tm_rows = 0;          // rows per pair chunk of k_tm (0 = 32)
+  int launch_threads = 256; // threads per block of the next launch (k_tm: 128)
   int halves = -1;   // -1: where it pays (halves_eligible), 0: never, 1: wherever the schedule allows
   std::vector<hipStream_t> chain_streams;   // streams of the chains below the first
   bool halves_captured[2] = {false, false};   // the batch graphs of size step_batch[b] the handle holds were captured in this form

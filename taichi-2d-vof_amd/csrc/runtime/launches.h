@@ -114,9 +114,9 @@ void launch(vof2d_ctx* h, int kid, void (*kernel)(KArgs...), dim3 grid, size_t l
   if (h->timed >= 0 && h->timed < vof2d_ctx::kMaxTimed) {
     const int k = h->timed++;
     h->tkid[k] = kid;
-    hipExtLaunchKernelGGL(kernel, grid, dim3(256), lds, h->stream, h->tev[2 * k], h->tev[2 * k + 1], 0, args...);
+    hipExtLaunchKernelGGL(kernel, grid, dim3(h->launch_threads), lds, h->stream, h->tev[2 * k], h->tev[2 * k + 1], 0, args...);
   } else {
-    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, h->stream, args...);
+    hipLaunchKernelGGL(kernel, grid, dim3(h->launch_threads), lds, h->stream, args...);
   }
 }
 
@@ -320,6 +320,29 @@ struct L {
     launch(h, kFctY, k_fct_y<T, V, POST, CORR>, dim3(blocks_rows(last - first + 1, h->nty, R)), 0, h->g, C(h),
            (const T*)F_<T>(h, fF), (const T*)F_<T>(h, fV), F_<T>(h, fF2), R, h->nty, (const T*)F_<T>(h, fUS),
            (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV), h->d_courant, first, last);
+  }
+  // k_transport of this step + k_momentum of the next in one launch (k_tm): reads fld[fF], fld[fUS], fld[fVS], fld[fP];
+  // writes fld[fF2], rhs, u*' / v*' into fld[fMX] / fld[fMY] (the caller alternates the pairs and swaps F), u and v
+  // only with STORE_UV; adapt_par: parity of the NEXT step (its planner block rides here as it does in k_momentum)
+  template <bool YFIRST, bool STORE_UV>
+  static void tm(vof2d_ctx* h, int adapt_par, int first = 1, int last = 0) {
+    if (last < first) { first = h->g.ilo; last = h->g.ihi; }
+    constexpr int ST = 64 * V - 2 * TmGeom::HF;
+    const int ntf = (h->g.ny + ST - 1) / ST;
+    const int R = h->tm_rows > 0 ? h->tm_rows : 32;
+    const TbPlan tp = tb_plan(h, adapt_par);
+    const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf) + (tp.masks ? 1u : 0u);
+    const bool bs = buffer_stores_ok(h) && (h->buf_stores & 1);
+    h->launch_threads = 128;
+    if (bs)
+      launch(h, kTransport, k_tm<T, V, YFIRST, STORE_UV, true>, dim3(pairs), 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+             (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
+             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last);
+    else
+      launch(h, kTransport, k_tm<T, V, YFIRST, STORE_UV, false>, dim3(pairs), 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+             (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
+             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last);
+    h->launch_threads = 256;
   }
   // update_uv + both sweeps + post_process_f in one pass (k_transport); reads fld[fF], writes fld[fF2]
   static int transport_rows(const vof2d_ctx* h) {

@@ -268,6 +268,42 @@ bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
   return ok;
 }
 
+// K steady-state steps of a full domain with the step boundary fused away: k_momentum, then per step two Jacobi
+// launches and k_tm (this step's transport + the next step's momentum), the last step ending in a plain k_transport
+// that stores u and v.  u*, v* alternate between their own arrays and the (otherwise verb-only) mx, my arrays; the
+// first k_momentum writes whichever pair makes the last step's land in their own.
+inline void swap_S(vof2d_ctx* h) {
+  void* t = h->fld[fUS]; h->fld[fUS] = h->fld[fMX]; h->fld[fMX] = t;
+  t = h->fld[fVS]; h->fld[fVS] = h->fld[fMY]; h->fld[fMY] = t;
+}
+inline bool tm_eligible(const vof2d_ctx* h) {
+  return h->fuse_tm && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 && h->d.jacobi_iters % 5 == 0 &&
+         h->d.jacobi_iters / 5 % 2 == 0 && h->g.nx >= 16;
+}
+template <typename T>
+void enqueue_steps_tm(vof2d_ctx* h, int64_t first_step, int K) {
+  const int nj = h->d.jacobi_iters / 5;
+  if ((K - 1) & 1) swap_S(h);
+  L<T>::momentum(h, true, (int)(first_step & 1));
+  for (int k = 0; k < K; ++k) {
+    const int64_t istep = first_step + k;
+    const int par = (int)(istep & 1);
+    int cur = fP, oth = fPT;
+    for (int j = 0; j < nj; ++j) {
+      L<T>::template jacobi_tb<5>(h, cur, oth, par);
+      const int t = cur; cur = oth; oth = t;
+    }
+    if (k < K - 1) {
+      if (istep % 2 == 0) L<T>::template tm<true, false>(h, par ^ 1); else L<T>::template tm<false, false>(h, par ^ 1);
+      swap_S(h);
+    } else {
+      if (istep % 2 == 0) L<T>::template transport<true>(h); else L<T>::template transport<false>(h);
+    }
+    swap_F(h);
+  }
+  // (the first swap and the K - 1 in the loop are an even number: the host's view of the pairs is back where it was)
+}
+
 int ensure_ok(vof2d_ctx* h) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

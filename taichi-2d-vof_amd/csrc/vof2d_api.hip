@@ -250,12 +250,15 @@ static void build_step_batches(vof2d_ctx* h) {
       hipGraphExec_t& slot = h->gbatch[b][(int)(first & 1)][ori_c];
       if (slot) continue;
       hipGraph_t graph = nullptr;
-      const bool chains = halves_eligible(h, h->step_batch[b]) && halves_prepare(h, h->step_batch[b]);
+      const bool fused_tm = tm_eligible(h);
+      const bool chains = !fused_tm && halves_eligible(h, h->step_batch[b]) && halves_prepare(h, h->step_batch[b]);
       if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { ok = false; break; }
       bool enq = true;
       if (chains) {
         h->halves_captured[b] = true;
         DISPATCH_T(h, enq = enqueue_steps_halves<double>(h, first, h->step_batch[b]), enq = enqueue_steps_halves<float>(h, first, h->step_batch[b]));
+      } else if (fused_tm) {
+        DISPATCH_T(h, enqueue_steps_tm<double>(h, first, h->step_batch[b]), enqueue_steps_tm<float>(h, first, h->step_batch[b]));
       } else
         for (int k = 0; k < h->step_batch[b]; ++k)
           DISPATCH_T(h, enqueue_step<double>(h, first + k, true, true), enqueue_step<float>(h, first + k, true, true));
@@ -619,7 +622,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
             : !strcmp(name, "momentum_rows") ? &h->mom_rows : !strcmp(name, "fctx_rows") ? &h->fctx_rows
             : !strcmp(name, "fctx_corr_rows") ? &h->fctx_corr_rows : !strcmp(name, "band_rows") ? &h->band_rows
             : !strcmp(name, "rows_per_wave") ? &h->rows_override : !strcmp(name, "fuse_transport") ? &h->fuse_transport
-            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : nullptr;
+            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : nullptr;
   if (knob) {
     *knob = (int)value;
     if (knob == &h->band_rows && *knob < 1) *knob = 1;

@@ -15,6 +15,7 @@
 //   momentum.h   k_momentum      (cal_nu_rho + get_normal_young + advect_upwind + rhs)
 //   jacobi.h     k_jacobi, k_jacobi_tb   (solve_p_jacobi, the north-star kernel)
 //   transport.h  k_fct_x, k_fct_y, k_transport   (update_uv + solve_VOF_rudman + post_process_f)
+//   fused_tm.h   k_tm   (k_transport of one step + k_momentum of the next, rows handed over through LDS)
 #pragma once
 #include "kernels/common.h"
 #include "kernels/verbs.h"
@@ -22,3 +23,4 @@
 #include "kernels/momentum.h"
 #include "kernels/jacobi.h"
 #include "kernels/transport.h"
+#include "kernels/fused_tm.h"

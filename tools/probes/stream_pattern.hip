@@ -20,7 +20,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 struct Args {
   const double* in[4];
-  double* out[3];
+  double* out[4];
   long pitch;
   int nx, ny, ntiles, R, L, nchunks;
   unsigned int* queue;   // [0] next item, [1] waves done (persistent mode)
@@ -127,20 +127,31 @@ int main(int argc, char** argv) {
   const size_t bytes = (size_t)(nx + 2) * pitch * 8;
   Args a{};
   std::vector<void*> bufs;
-  for (int k = 0; k < 7; ++k) {
+  for (int k = 0; k < 8; ++k) {
     void* p;
     hipMalloc(&p, bytes + bytes / 4);
     hipMemset(p, 0, bytes);
     bufs.push_back(p);
   }
   for (int k = 0; k < 4; ++k) a.in[k] = (const double*)bufs[k];
-  for (int k = 0; k < 3; ++k) a.out[k] = (double*)bufs[4 + k];
+  for (int k = 0; k < 4; ++k) a.out[k] = (double*)bufs[4 + k];
   hipMalloc(&a.queue, 64);
   hipMemset(a.queue, 0, 64);
   a.pitch = pitch; a.nx = nx; a.ny = ny; a.ntiles = ny / 128;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<Cfg> cfgs;
+  const bool fuse = argc > 2 && !strcmp(argv[2], "fuse");   // what a fused k_transport + next k_momentum would move: 4 in / 4 out against 4 / 3 + 3 / 3
+  if (fuse) {
+    for (int rep = 0; rep < 2; ++rep) {
+      cfgs.push_back({4, 3, 16, 6, 3, 0, 1, 0, 4, 0, 0, 0, 0, 112, 4, 59});
+      cfgs.push_back({3, 3, 14, 7, 3, 0, 1, 0, 4, 0, 0, 0, 0, 124, 1, 62});
+      cfgs.push_back({4, 4, 16, 13, 3, 0, 1, 0, 4, 0, 0, 0, 0, 112, 4, 59});
+      cfgs.push_back({4, 4, 32, 13, 3, 0, 1, 0, 4, 0, 0, 0, 0, 112, 4, 59});
+      cfgs.push_back({4, 4, 32, 13, 2, 0, 1, 0, 4, 0, 0, 0, 0, 112, 4, 59});
+      cfgs.push_back({4, 1, 16, 6, 3, 0, 1, 0, 4, 0, 0, 0, 0, 112, 4, 59});
+    }
+  }
   const bool stat = argc > 2 && !strcmp(argv[2], "static");   // persistent waves with a static stride against one wave per chunk
   if (stat) {
     for (int rep = 0; rep < 2; ++rep)
@@ -162,7 +173,7 @@ int main(int argc, char** argv) {
         cfgs.push_back({4, 3, R, R == 16 ? 6 : 0, 3, 0, 1, 0, 4, 0, nxo, 0, 0, 128, 0, 63});
         cfgs.push_back({2, 1, R, R == 16 ? 10 : 0, 3, 0, 1, 0, 4, 0, nxo, 0, 0, 128, 0, 63});
       }
-  } else if (!stat)
+  } else if (!stat && !fuse)
   for (int R : {2, 51})
     for (int L : {0, 10}) {
       if (R == 2 && L) continue;
@@ -172,8 +183,8 @@ int main(int argc, char** argv) {
       cfgs.push_back({2, 1, R, L, 3, 0, 1, 0, 4, 0, 0, 0, 0, 112, 4, 59});    // 112 = 7 x 128 B
       cfgs.push_back({2, 1, R, L, 3, 0, 1, 0, 4, 0, 0, 0, 0, 96, 8, 55});     // 96 = 6 x 128 B
     }
-  if (!mall && !stat) for (int ts : {128, 120, 112}) cfgs.push_back({4, 3, 16, 6, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
-  if (!mall && !stat) for (int ts : {128, 124, 112}) cfgs.push_back({3, 3, 14, 7, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
+  if (!mall && !stat && !fuse) for (int ts : {128, 120, 112}) cfgs.push_back({4, 3, 16, 6, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
+  if (!mall && !stat && !fuse) for (int ts : {128, 124, 112}) cfgs.push_back({3, 3, 14, 7, 3, 0, 1, 0, 4, 0, 0, 0, 0, ts, (128 - ts) / 4, 63 - (128 - ts) / 4});
   for (const Cfg& c : cfgs) {
     const int nxr = c.nxo ? c.nxo : nx;
     a.nx = nxr; a.wpb = c.wpb; a.sync_rows = c.sync; a.work = c.work; a.stagger = c.stagger; a.tstride = c.tstride; a.vlo = c.vlo; a.vhi = c.vhi; a.ntiles = (ny + c.tstride - 1) / c.tstride; a.km = 0.999999; a.ka = 1e-9;
@@ -184,13 +195,13 @@ int main(int argc, char** argv) {
     if (c.persistent) blocks = std::min<unsigned>(blocks, 256u * c.wps);
     auto launch = [&]() {
 #define GO(NI, NO, DD) hipLaunchKernelGGL((k_stream<NI, NO, DD>), dim3(blocks), dim3(64 * c.wpb), lds * c.wpb / 4, 0, a)
-      if (c.nin == 4 && c.D == 1) GO(4, 3, 1); else if (c.nin == 4) GO(4, 3, 2);
+      if (c.nin == 4 && c.nout == 4) GO(4, 4, 1); else if (c.nin == 4 && c.nout == 1) GO(4, 1, 1); else if (c.nin == 4 && c.D == 1) GO(4, 3, 1); else if (c.nin == 4) GO(4, 3, 2);
       else if (c.nin == 3 && c.D == 1) GO(3, 3, 1); else if (c.nin == 3) GO(3, 3, 2);
       else if (c.D == 1) GO(2, 1, 1); else GO(2, 1, 2);
     };
     if (lds > 64 * 1024) {
 #define ATTR(NI, NO, DD) hipFuncSetAttribute(reinterpret_cast<const void*>(k_stream<NI, NO, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-      ATTR(4, 3, 1); ATTR(4, 3, 2); ATTR(3, 3, 1); ATTR(3, 3, 2); ATTR(2, 1, 1); ATTR(2, 1, 2);
+      ATTR(4, 4, 1); ATTR(4, 1, 1); ATTR(4, 3, 1); ATTR(4, 3, 2); ATTR(3, 3, 1); ATTR(3, 3, 2); ATTR(2, 1, 1); ATTR(2, 1, 2);
     }
     for (int w = 0; w < 3; ++w) launch();
     hipDeviceSynchronize();
