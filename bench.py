@@ -299,6 +299,39 @@ def supervise(a, rank):
 
 # --------------------------------------------------------------------------------------------------
 # single-GPU extras
+HANDLE_WARM_STEPS = 41   # 1 eager step + 5 batches of 8: the step graphs of both forms captured, four of the batches timed by the handle
+
+
+def warm_handle(e, ic, nx, ny, dtype):
+    """A handle captures its step graphs on its first steady-state steps and, on a large fp64 grid, times its two batch
+    forms against each other on the next 32 (chains of the four kernels against k_tm) -- once, 40-80 ms
+    all told.  A bench of a few dozen steps is not the place to charge that to, so the handle is warmed and then put
+    back to the initial state: all-zero F, u, v, p as a new handle holds them, set_init_F (which, like 2dvof.py:141-147,
+    only writes the liquid cells of the dam), istep = 0.  tests/test_parity_gpu.py checks that a handle treated like
+    this repeats a new handle's run value for value.  Returns the wall time of the warm steps in ms."""
+    import numpy as np
+    e.sync()
+    t0 = time.perf_counter()
+    e.step(HANDLE_WARM_STEPS)       # (one eager step and an even number of fused ones: the F / twin pair is back in place)
+    e.sync()
+    ms = 1e3 * (time.perf_counter() - t0)
+    zeros = np.zeros((nx + 2, ny + 2), dtype=np.float64 if dtype == "f64" else np.float32)
+    for f in ("F", "u", "v", "p"):
+        e.set(f, zeros)
+    del zeros
+    e.set_init_F(ic)
+    e.istep = 0
+    e.sync()
+    return ms
+
+
+def _batch_form(form):
+    halves, choice, tm_steps = form
+    if choice == 1 or (choice < 0 and tm_steps > 0):
+        return "k_tm batch graphs (k_transport + the next step's k_momentum as one kernel)"
+    return "chain batch graphs (every kernel as launches on row blocks)" if halves else "one-chain batch graphs"
+
+
 def timed_steps(eng, warmup, steps):
     eng.step(warmup)
     eng.sync()
@@ -313,26 +346,9 @@ def sustained_record(api, nx, ny, dtype, ic, local, jacobi_iters, dt, nsteps, bl
     block): the default timing window (a few dozen steps right after the start) does not see the
     regime in which the decaying front of the pressure iteration crosses the grid."""
     from vof2d.engine import Engine, make_desc
-    import numpy as np
     e = Engine(api, make_desc(api, nx, ny, dtype, "f32", device=local, jacobi_iters=jacobi_iters, dt=dt))
-    # A handle captures its step graphs once, on its first steady-state steps (the two-chain batch graphs of a large
-    # grid: 20-35 ms); a run of 1000 steps is not the place to charge that to.  Warm the handle (one eager step and an
-    # even number of fused ones: the F / twin pair is back in place), then put the initial state back (all-zero F, u,
-    # v, p as a new handle holds them, then set_init_F -- which, like 2dvof.py:141-147, only writes the liquid cells
-    # of the dam) and count from step 1.
     e.set_init_F(ic)
-    e.sync()
-    t0 = time.perf_counter()
-    e.step(13)
-    e.sync()
-    warm_ms = 1e3 * (time.perf_counter() - t0)
-    zeros = np.zeros((nx + 2, ny + 2), dtype=np.float64 if dtype == "f64" else np.float32)
-    for f in ("F", "u", "v", "p"):
-        e.set(f, zeros)
-    del zeros
-    e.set_init_F(ic)
-    e.istep = 0
-    e.sync()
+    warm_ms = warm_handle(e, ic, nx, ny, dtype)
     blocks = []
     t_all = time.perf_counter()
     for _ in range(max(1, nsteps // block)):
@@ -343,13 +359,14 @@ def sustained_record(api, nx, ny, dtype, ic, local, jacobi_iters, dt, nsteps, bl
     total = time.perf_counter() - t_all
     n = block * len(blocks)
     viol = e.get_counter("courant_violations")
+    e_form = (e.get_param("overlap_halves"), e.get_counter("tm_choice"), e.get_counter("tm_steps"))
     e.close()
     return {"steps": n, "block": block, "ms_per_step_blocks": [round(b, 4) for b in blocks],
             "ms_per_step": 1e3 * total / n, "ms_per_step_worst_block": max(blocks),
             "value": nx * ny * n / total, "unit": "cell-updates/s", "courant_violations": viol,
-            "warmup_13_steps_ms": round(warm_ms, 2),
-            "note": "steps 1..%d from the initial state on a warm handle (13 steps, then F = u = v = p = 0, set_init_F, "
-                    "istep = 0: its step graphs are captured), wall clock incl. one sync per block" % n}
+            "handle_warm_steps_ms": round(warm_ms, 2), "batch_form": _batch_form(e_form),
+            "note": "steps 1..%d from the initial state on a warm handle (%d steps, then F = u = v = p = 0, set_init_F, "
+                    "istep = 0: its step graphs are captured and its batch form chosen), wall clock incl. one sync per block" % (n, HANDLE_WARM_STEPS)}
 
 
 def residual_solve_1024(api, local, dtype="f64", tol=1e-6, cap=3000000, every=5000):
@@ -382,10 +399,13 @@ def single_gpu_reference(api, n, dtype, ic, local, jacobi_iters, dt, steps=12):
     from vof2d.engine import Engine, make_desc
     e = Engine(api, make_desc(api, n, n, dtype, "f32", device=local, jacobi_iters=jacobi_iters, dt=dt))
     e.set_init_F(ic)
+    warm_handle(e, ic, n, n, dtype)
+    steps = max(steps, 24)
     el = timed_steps(e, 3, steps)
+    form = _batch_form((e.get_param("overlap_halves"), e.get_counter("tm_choice"), e.get_counter("tm_steps")))
     e.close()
     return {"workload": "%dx%d -ic %d %s dt %g, single strip (the grid bench.py --gpus N > 1 strong-scales)" % (n, n, ic, dtype, dt),
-            "value": n * n * steps / el, "unit": "cell-updates/s", "ms_per_step": 1e3 * el / steps, "steps": steps}
+            "value": n * n * steps / el, "unit": "cell-updates/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "batch_form": form}
 
 
 def fast_leg(a):
@@ -402,6 +422,7 @@ def fast_leg(a):
     e = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=int(os.environ.get("LOCAL_RANK", "0")),
                               jacobi_iters=a.jacobi_iters, dt=a.dt if a.dt > 0 else 4e-6))
     e.set_init_F(a.ic)
+    warm_handle(e, a.ic, nx, ny, a.dtype)
     el = timed_steps(e, a.warmup, a.steps)
     e.close()
     out = {"build": "hipcc -ffp-contract=fast (FMA contraction; not bit-identical to the reference's operation order)",
@@ -506,6 +527,7 @@ def main():
         api = hip_api()
         eng = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters, dt=dt))
         eng.set_init_F(a.ic)
+        handle_warm_ms = warm_handle(eng, a.ic, nx, ny, a.dtype)
         elapsed = timed_steps(eng, a.warmup, a.steps)
         solver = None
     native_ok = False
@@ -748,7 +770,9 @@ def main():
                 # two-chain: every kernel of a step as two launches (rows above / below a moving boundary) on two
                 # streams, the lower chain one kernel behind the upper; one-chain: four launches per
                 # step, one after the other (small grids, strips, VOF2D_OVERLAP_HALVES=0)
-                "step_schedule": ("two-chain batch graphs" if eng.get_param("overlap_halves") else "one-chain batch graphs") if not dist_path else "strips"},
+                "step_schedule": _batch_form((eng.get_param("overlap_halves"), eng.get_counter("tm_choice"), eng.get_counter("tm_steps"))) if not dist_path else "strips",
+                "handle_warm_steps": HANDLE_WARM_STEPS if not dist_path else None,
+                "handle_warm_ms": round(handle_warm_ms, 2) if not dist_path else None},
             # `roofline` = the Poisson Jacobi kernel THE STEP RUNS, k_jacobi_tb (five sweeps per launch): algorithmic bytes =
             # 3 arrays x sizeof(T) x cells per launch (read p, read rhs, write p after five sweeps; SURVEY 8d's 24 B rule
             # per launch), duration = its average dispatch over the in-situ profile above (HIP events on the launch

@@ -168,7 +168,16 @@ struct vof2d_ctx {
   // knob "overlap_halves": the batch graphs run every kernel of a step as two launches, on the rows above and below a
   // boundary that moves up by kHalvesDrift rows from kernel to kernel, the upper chain on `stream`, the lower on
   // `stream2`; a lower launch waits for the upper launch of the kernel before it only (enqueue_steps_halves)
-  int fuse_tm = 0;          // knob: batch graphs run k_transport + the next step's k_momentum as one kernel (k_tm)
+  // knob "fuse_tm": the batch graphs run k_transport + the next step's k_momentum as one kernel (k_tm, kernels/fused_tm.h):
+  // 0 never, 1 wherever the schedule allows, -1 (default) on large fp64 grids after timing both forms on the handle's
+  // own data: four 8-step batches alternate between the forms, the faster one stays (vof_step)
+  int fuse_tm = -1;
+  hipGraphExec_t gbatch_tm[kStepBatches][2][2] = {};   // the k_tm form of gbatch
+  int tune_n = 0;            // timed batches so far (even: chains / plain, odd: k_tm); 4: ready to decide; 5: decided
+  int tm_choice = 0;         // the form that stays
+  hipEvent_t tune_ev[8] = {};
+  float tune_ms[2] = {0.f, 0.f};
+  int64_t tm_steps = 0;      // steps replayed from k_tm batch graphs (counter "tm_steps")
   int tm_rows = 0;          // rows per pair chunk of k_tm (0 = 32)
   int launch_threads = 256; // threads per block of the next launch (k_tm: 128)
   int halves = -1;   // -1: where it pays (halves_eligible), 0: never, 1: wherever the schedule allows

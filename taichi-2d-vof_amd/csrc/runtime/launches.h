@@ -329,7 +329,13 @@ struct L {
     if (last < first) { first = h->g.ilo; last = h->g.ihi; }
     constexpr int ST = 64 * V - 2 * TmGeom::HF;
     const int ntf = (h->g.ny + ST - 1) / ST;
-    const int R = h->tm_rows > 0 ? h->tm_rows : 32;
+    // pair chunks: about two residency rounds (6 pairs per CU: 24 KB of LDS each) -- one round of long chunks is slow
+    // (3072^2: 64 rows 0.432 ms/step, 32 rows 0.346; 4096^2: 96 rows 0.627, 64 rows 0.538, 32 rows 0.554)
+    int R = h->tm_rows;
+    if (R <= 0) {
+      R = (int)(((long)(h->g.ihi - h->g.ilo + 1) * ntf / 2765 + 4) / 8 * 8);
+      R = R < 16 ? 16 : (R > 64 ? 64 : R);
+    }
     const TbPlan tp = tb_plan(h, adapt_par);
     const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf) + (tp.masks ? 1u : 0u);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 1);

@@ -188,6 +188,21 @@ constexpr int kHalvesDrift = 8;
 // Measured (tools/probes/halves_sweep.py, ms/step off -> on): 4096^2 fp64 dam-break 0.579 -> 0.560 (late) / 0.592 -> 0.562
 // (front), bubble 0.694 -> 0.622, 4096^2 fp32 0.367 -> 0.339, 8192^2 2.30 -> 2.24, 3072^2 0.353 -> 0.344, 2560^2 0.261 -> 0.251;
 // 2048^2 fp64 0.172 -> 0.190 and 1024^2 0.087 -> 0.097 (half launches too small to fill the chip): on from 6 M cells and 1024 rows per chain.
+inline void swap_S(vof2d_ctx* h) {
+  void* t = h->fld[fUS]; h->fld[fUS] = h->fld[fMX]; h->fld[fMX] = t;
+  t = h->fld[fVS]; h->fld[fVS] = h->fld[fMY]; h->fld[fMY] = t;
+}
+inline bool tm_eligible(const vof2d_ctx* h) {
+  return h->fuse_tm != 0 && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 && h->d.jacobi_iters % 5 == 0 &&
+         h->d.jacobi_iters / 5 % 2 == 0 && h->g.nx >= 16;
+}
+// fuse_tm = -1: the handle times both forms where k_tm has a chance -- large fp64 grids (tools/probes/halves_sweep.py,
+// ms/step one chain / chains / k_tm: 4096^2 dam-break 0.601 / 0.576 / 0.547, 8192^2 2.27 / 2.31 / 1.93, but 4096^2
+// rising bubble 0.682 / 0.612 / 0.808 -- mostly liquid: the pair is bound by its instruction issue --, 4096^2 fp32
+// 0.364 / 0.337 / 0.361, 3072^2 0.351 / 0.346 / 0.346, 2048^2 0.168 / - / 0.188)
+inline bool tm_auto(const vof2d_ctx* h) {
+  return h->fuse_tm < 0 && tm_eligible(h) && h->d.dtype == VOF_F64 && (long)h->g.nx * h->g.ny >= 12000000L && h->g.nx >= 2048;
+}
 // chains: two; three from 32 M cells (8192^2: 2.30 ms/step in one chain, 2.29 in two, 2.16 in three, 2.17 in four; 4096^2: 0.595 / 0.574 /
 // 0.566 / 0.579 inside the front, 0.582 / 0.562 / 0.565 / 0.583 behind it); knob values >= 2 force a count
 inline int halves_chains(const vof2d_ctx* h) {
@@ -243,6 +258,8 @@ bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
     for (int p = 0; p < P - 1; ++p) s[p] -= kHalvesDrift;
     ++n;
   };
+  // (k_tm inside the chains was measured and is slower than either alone -- 4096^2: 0.658 ms/step against 0.543 for
+  // k_tm in one chain and 0.563 for chains of the four kernels: a pair's launch wants the whole chip)
   for (int k = 0; k < K && ok; ++k) {
     const int64_t istep = first_step + k;
     const int par = (int)(istep & 1);
@@ -272,14 +289,6 @@ bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
 // launches and k_tm (this step's transport + the next step's momentum), the last step ending in a plain k_transport
 // that stores u and v.  u*, v* alternate between their own arrays and the (otherwise verb-only) mx, my arrays; the
 // first k_momentum writes whichever pair makes the last step's land in their own.
-inline void swap_S(vof2d_ctx* h) {
-  void* t = h->fld[fUS]; h->fld[fUS] = h->fld[fMX]; h->fld[fMX] = t;
-  t = h->fld[fVS]; h->fld[fVS] = h->fld[fMY]; h->fld[fMY] = t;
-}
-inline bool tm_eligible(const vof2d_ctx* h) {
-  return h->fuse_tm && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 && h->d.jacobi_iters % 5 == 0 &&
-         h->d.jacobi_iters / 5 % 2 == 0 && h->g.nx >= 16;
-}
 template <typename T>
 void enqueue_steps_tm(vof2d_ctx* h, int64_t first_step, int K) {
   const int nj = h->d.jacobi_iters / 5;
@@ -355,6 +364,11 @@ void destroy_graphs(vof2d_ctx* h) {
     for (int k = 0; k < 2; ++k)
       for (int o = 0; o < 2; ++o)
         if (h->gbatch[b][k][o]) { (void)hipGraphExecDestroy(h->gbatch[b][k][o]); h->gbatch[b][k][o] = nullptr; }
+  for (int b = 0; b < vof2d_ctx::kStepBatches; ++b)
+    for (int k = 0; k < 2; ++k)
+      for (int o = 0; o < 2; ++o)
+        if (h->gbatch_tm[b][k][o]) { (void)hipGraphExecDestroy(h->gbatch_tm[b][k][o]); h->gbatch_tm[b][k][o] = nullptr; }
+  h->tune_n = 0; h->tune_ms[0] = h->tune_ms[1] = 0.f;   // (a changed knob changes what is being compared)
   h->halves_captured[0] = h->halves_captured[1] = false;
   h->batching = true;   // (a parameter change may be what a capture tripped over: try again)
   for (int k = 0; k < 5; ++k)

@@ -116,6 +116,7 @@ int vof_destroy(vof2d_handle h) {
   for (int k = 0; k < 2 * vof2d_ctx::kMaxTimed; ++k)
     if (h->tev[k]) (void)hipEventDestroy(h->tev[k]);
   for (hipEvent_t e : h->hev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->tune_ev) if (e) (void)hipEventDestroy(e);
   for (hipStream_t st : h->chain_streams) (void)hipStreamDestroy(st);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -192,7 +193,7 @@ int vof_update_uv(vof2d_handle h) {
 // stale: drop the graphs (they are re-captured on the next vof_step / vof_step_phase).
 static void sweep_swapped(vof2d_handle h) {
   bool any = h->gexec[0][0] || h->gexec[0][1] || h->gexec[1][0] || h->gexec[1][1];
-  for (int k = 0; k < 4 * vof2d_ctx::kStepBatches; ++k) any = any || h->gbatch[k / 4][(k / 2) % 2][k % 2];
+  for (int k = 0; k < 4 * vof2d_ctx::kStepBatches; ++k) any = any || h->gbatch[k / 4][(k / 2) % 2][k % 2] || h->gbatch_tm[k / 4][(k / 2) % 2][k % 2];
   for (int k = 0; k < 5; ++k) any = any || h->gphase[k];
   for (int k = 0; k < 20; ++k) any = any || h->gxchg[k / 10][(k / 2) % 5][k % 2];
   if (!any) return;
@@ -238,7 +239,8 @@ int vof_post_process_f(vof2d_handle h) {
 // was moved alone (vof_set_istep) gets the other two on its next steady-state step.  Captures enqueue nothing.  Any
 // failure on the way ends the capture, puts the F / twin pair back, switches batching off for the handle and leaves
 // the single-step graphs (or eager launches) to carry on: never an error of vof_step.
-static void build_step_batches(vof2d_ctx* h) {
+static void build_step_batches(vof2d_ctx* h, int variant /* 0: chains or the plain sequence, 1: k_tm */) {
+  auto& GB = variant ? h->gbatch_tm : h->gbatch;
   void* const f0 = h->fld[fF];
   void* const f1 = h->fld[fF2];
   bool ok = true;
@@ -247,10 +249,10 @@ static void build_step_batches(vof2d_ctx* h) {
     const int64_t first = h->istep + c;
     const int ori_c = h->fld[fF] == h->f_home ? 0 : 1;
     for (int b = 0; b < vof2d_ctx::kStepBatches && ok; ++b) {
-      hipGraphExec_t& slot = h->gbatch[b][(int)(first & 1)][ori_c];
+      hipGraphExec_t& slot = GB[b][(int)(first & 1)][ori_c];
       if (slot) continue;
       hipGraph_t graph = nullptr;
-      const bool fused_tm = tm_eligible(h);
+      const bool fused_tm = variant == 1;
       const bool chains = !fused_tm && halves_eligible(h, h->step_batch[b]) && halves_prepare(h, h->step_batch[b]);
       if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { ok = false; break; }
       bool enq = true;
@@ -276,7 +278,7 @@ static void build_step_batches(vof2d_ctx* h) {
     (void)hipGetLastError();
     for (int b = 0; b < vof2d_ctx::kStepBatches; ++b)
       for (int k = 0; k < 4; ++k)
-        if (h->gbatch[b][k >> 1][k & 1]) { (void)hipGraphExecDestroy(h->gbatch[b][k >> 1][k & 1]); h->gbatch[b][k >> 1][k & 1] = nullptr; }
+        if (GB[b][k >> 1][k & 1]) { (void)hipGraphExecDestroy(GB[b][k >> 1][k & 1]); GB[b][k >> 1][k & 1] = nullptr; }
     h->batching = false;
     if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] step batches could not be captured: one graph launch per step\n");
   }
@@ -307,16 +309,48 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       // Parity and orientation flip together from step to step, so two (parity, orientation) pairs are
       // reachable; the batch graphs of both are captured the first time a steady-state step comes by (captures
       // enqueue nothing), so that no later call pays for an instantiation in the middle of a run.
-      if (h->batching && !h->gbatch[0][par][h->fld[fF] == h->f_home ? 0 : 1]) build_step_batches(h);
+      // Which form of the batch graphs: k_tm (variant 1) where the knob says so; with the knob on "auto" the handle
+      // first times both on its own data -- four 8-step batches, alternating -- and keeps the faster (tm_auto).
+      int variant = (h->fuse_tm > 0 && tm_eligible(h)) ? 1 : 0;
+      bool timed = false;
+      if (tm_auto(h)) {
+        if (h->tune_n == 4) {
+          bool done = hipEventSynchronize(h->tune_ev[7]) == hipSuccess;
+          for (int k = 0; k < 4 && done; ++k) {
+            float ms = 0.f;
+            done = hipEventElapsedTime(&ms, h->tune_ev[2 * k], h->tune_ev[2 * k + 1]) == hipSuccess;
+            h->tune_ms[k & 1] += ms;
+          }
+          h->tm_choice = (done && h->tune_ms[1] < 0.99f * h->tune_ms[0]) ? 1 : 0;
+          h->tune_n = 5;
+          if (!done) (void)hipGetLastError();
+          if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] batch forms timed: %.3f ms (chains / plain) vs %.3f ms (k_tm) per 16 steps -> %s\n", h->tune_ms[0], h->tune_ms[1], h->tm_choice ? "k_tm" : "chains / plain");
+        }
+        if (h->tune_n < 4) { variant = h->tune_n & 1; timed = nsteps - s >= h->step_batch[0]; if (!timed) variant = 0; }
+        else variant = h->tm_choice;
+      }
+      auto& GB = variant ? h->gbatch_tm : h->gbatch;
+      if (h->batching && !GB[0][par][h->fld[fF] == h->f_home ? 0 : 1]) build_step_batches(h, variant);
       const int ori = h->fld[fF] == h->f_home ? 0 : 1;
       bool batched = false;
       for (int b = 0; b < vof2d_ctx::kStepBatches && !batched; ++b) {
         const int K = h->step_batch[b];
-        if (nsteps - s < K || !h->gbatch[b][par][ori]) continue;
-        HIPCHK(h, hipGraphLaunch(h->gbatch[b][par][ori], h->stream));
+        if (nsteps - s < K || !GB[b][par][ori]) continue;
+        const bool time_it = timed && b == 0 && h->batching;
+        if (time_it) {
+          for (int k = 0; k < 2; ++k)
+            if (!h->tune_ev[2 * h->tune_n + k] && hipEventCreate(&h->tune_ev[2 * h->tune_n + k]) != hipSuccess) return fail(h, VOF_EHIP, "hipEventCreate");
+          HIPCHK(h, hipEventRecord(h->tune_ev[2 * h->tune_n], h->stream));
+        }
+        HIPCHK(h, hipGraphLaunch(GB[b][par][ori], h->stream));
+        if (time_it) {
+          HIPCHK(h, hipEventRecord(h->tune_ev[2 * h->tune_n + 1], h->stream));
+          h->tune_n += 1;
+        }
         h->istep += K - 1;
         s += K - 1;
-        if (h->halves_captured[b]) h->halves_steps += K;
+        if (variant) h->tm_steps += K;
+        else if (h->halves_captured[b]) h->halves_steps += K;
         batched = true;
       }
       if (batched) {
@@ -667,6 +701,14 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
     HIPCHK(h, hipMemcpyAsync(&v, h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64), sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *value = (int64_t)v;
+    return VOF_OK;
+  }
+  if (!strcmp(name, "tm_steps")) {   // steps replayed from batch graphs in the k_tm form
+    *value = h->tm_steps;
+    return VOF_OK;
+  }
+  if (!strcmp(name, "tm_choice")) {   // -1: the forms are still being timed (or never will be), 0 / 1: the form that stayed
+    *value = (tm_auto(h) && h->tune_n == 5) ? h->tm_choice : -1;
     return VOF_OK;
   }
   if (!strcmp(name, "halves_steps")) {   // steps replayed from batch graphs in the two-chain form (enqueue_steps_halves)

@@ -72,7 +72,8 @@ def test_plan_on_equals_plan_off_at_baseline_sizes(hip_api, n, steps, checks, dt
     on = engine(hip_api, n, n, "f64", "f32", ic=1, **kw)
     off = engine(hip_api, n, n, "f64", "f32", ic=1, **kw)
     off.set_param("jacobi_tb_adapt", 0)
-    off.set_param("overlap_halves", 0)               # (`on` also runs the two-chain batch graphs, the default at these sizes)
+    off.set_param("overlap_halves", 0)               # (`on` runs the default at these sizes: chains of launches or k_tm,
+    off.set_param("fuse_tm", 0)                      #  whichever the handle finds faster; `off` the plain four-kernel sequence)
     active = 0
     for st in checks:
         while on.istep < st:
@@ -87,7 +88,8 @@ def test_plan_on_equals_plan_off_at_baseline_sizes(hip_api, n, steps, checks, dt
                 assert _tiny_cells(x) > 10000, "no tiny-value front at step %d" % st
             del x, y
     assert active >= len(checks) and off.get_counter("tb_plan_active") == 0
-    assert on.get_counter("halves_steps") >= steps - 20 and off.get_counter("halves_steps") == 0
+    assert on.get_counter("halves_steps") + on.get_counter("tm_steps") >= steps - 20 and on.get_counter("halves_steps") >= 16 and on.get_counter("tm_steps") >= 16
+    assert on.get_counter("tm_choice") in (0, 1) and off.get_counter("halves_steps") + off.get_counter("tm_steps") == 0
     F = on.get("F")
     assert F.min() >= 0.0 and F.max() <= 1.0 and on.get_counter("courant_violations") == 0
 

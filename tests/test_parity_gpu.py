@@ -723,6 +723,7 @@ def test_overlap_halves_change_no_value(hip_api, oracle_api, dtype, ic, nx, ny, 
     work plan (one plan per step, made by the upper k_momentum launch, clipped by each launch to its rows)."""
     kw = {"gy": 0.0} if ring else {}
     a = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
+    a.set_param("fuse_tm", 0)
     a.set_param("overlap_halves", chains)         # (odd ny: the exec-masked store forms; 3 / 4 chains: every middle chain has two moving boundaries)
     b = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
     b.set_param("overlap_halves", 0)
@@ -762,6 +763,7 @@ def test_warm_handle_reset_to_the_initial_state_repeats_the_run(hip_api, dtype, 
     fresh = engine(hip_api, nx, ny, dtype, "f32", ic=1)
     warm = engine(hip_api, nx, ny, dtype, "f32", ic=1)
     warm.set_param("overlap_halves", 1)
+    warm.set_param("fuse_tm", 0)
     warm.step(13)
     zeros = np.zeros((nx + 2, ny + 2))
     for f in ("F", "u", "v", "p"):
@@ -773,3 +775,46 @@ def test_warm_handle_reset_to_the_initial_state_repeats_the_run(hip_api, dtype, 
         warm.step(st - warm.istep)
         assert_fields_same(warm, fresh, ctx="%s step %d" % (dtype, st))
     assert warm.get_counter("halves_steps") > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ic,nx,ny,ring", [("f64", 1, 448, 400, False), ("f32", 2, 300, 333, False), ("f64", 3, 260, 1100, True),
+                                                  ("f32", 1, 500, 666, True), ("f64", 2, 96, 130, False)])
+def test_fused_transport_momentum_changes_no_value(hip_api, oracle_api, dtype, ic, nx, ny, ring):
+    """k_tm (kernels/fused_tm.h): k_transport of a step and k_momentum of the next as ONE kernel -- a workgroup is a pair
+    of waves on one tile, the transport wave five rows ahead of the momentum wave, F'', u, v handed over through a ring in
+    LDS; u, v reach memory only at the end of a batch, u*, v* alternate between two pairs of arrays.  Forced here (the
+    default times it against the other form on large fp64 grids only), against the plain sequence and the oracle:
+    all state fields and the step's intermediates, at the ends of 8- and 2-step batches and after single steps;
+    even and odd ny (buffer stores / exec-masked stores), a ring of tiny pressure values (the planner block rides in
+    k_tm), a grid with a single chunk row."""
+    kw = {"gy": 0.0} if ring else {}
+    a = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
+    a.set_param("overlap_halves", 0)
+    a.set_param("fuse_tm", 1)
+    b = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
+    b.set_param("overlap_halves", 0)
+    b.set_param("fuse_tm", 0)
+    o = engine(oracle_api, nx, ny, dtype, "f32", ic=ic, **kw)
+    if ring:
+        tiny = 1e-290 if dtype == "f64" else 1e-32
+        rng = np.random.default_rng(nx + ny)
+        p0 = np.zeros((nx + 2, ny + 2))
+        i, j = np.meshgrid(np.arange(nx + 2), np.arange(ny + 2), indexing="ij")
+        r = np.hypot(i - 0.5 * nx, j - 0.4 * ny)
+        band = (r > 0.2 * min(nx, ny)) & (r < 0.4 * min(nx, ny))
+        p0[band] = tiny * rng.uniform(0.5, 2.0, size=int(band.sum()))
+        p0[r <= 0.2 * min(nx, ny)] = 1.0
+        for e in (a, b, o):
+            e.set("p", p0)
+    planned = 0
+    for st in (1, 3, 11, 12, 22, 23, 40):
+        for e in (a, b, o):
+            e.step(st - e.istep)
+        planned += a.get_counter("tb_plan_active")
+        assert_fields_same(a, b, STATE + ("u_star", "v_star", "rhs"), ctx="k_tm on / off, %s %dx%d step %d" % (dtype, nx, ny, st))
+        assert_fields_same(a, o, ctx="k_tm / oracle, %s %dx%d step %d" % (dtype, nx, ny, st))
+    assert a.get_counter("tm_steps") == 2 + 8 + 10 + 16 and b.get_counter("tm_steps") == 0
+    assert a.get_counter("courant_violations") == o.get_counter("courant_violations")
+    if ring:
+        assert planned >= 2, planned

@@ -19,7 +19,7 @@ def mk(tm, **kw):
     e.set_init_F(ic)
     return e
 kw = dict((k, float(v)) for k, v in (x.split('=') for x in sys.argv[6:]))
-a, b = mk(1, **kw), mk(0, **kw)
+a, b = mk(1, **kw), mk(0)
 for st in (1, 3, 11, 12, 22, 23, 40, 41, 57):
     a.step(st - a.istep); b.step(st - b.istep)
     bad = []
