@@ -79,6 +79,7 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
       h->own_stream = true;
     }
     if (const char* ev = getenv("VOF2D_OVERLAP_HALVES")) h->halves = atoi(ev);   // (profiling runs: per-kernel counters want one kernel at a time)
+    if (const char* ev = getenv("VOF2D_FUSE_TM")) h->fuse_tm = atoi(ev);
 #ifdef VOF_ARENA_EXP   // placement experiment (tools/probes/arena_modes.py): shift of the whole arena, extra bytes between fields
     const size_t shift_ = getenv("VOF2D_ARENA_SHIFT") ? (size_t)atoll(getenv("VOF2D_ARENA_SHIFT")) : 0;
     const size_t skew_ = getenv("VOF2D_FIELD_SKEW") ? (size_t)atoll(getenv("VOF2D_FIELD_SKEW")) : 0;

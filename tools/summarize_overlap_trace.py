@@ -30,7 +30,7 @@ for spec in a.traces:
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("<")[0].replace("void vof::", "").strip()))
     rows.sort()
-    mom = [i for i, r in enumerate(rows) if r[2] == "k_momentum"]
+    mom = [i for i, r in enumerate(rows) if r[2] in ("k_momentum", "k_tm")]     # (one dispatch per step starts with either)
     per_step = 2 if len(mom) > 1.5 * a.steps else 1      # (two-chain: two dispatches per kernel and step; the first step
     for st0, st1 in wins:                                #  and what no batch holds run one-chain: a window's ends are off by a step at most)
         n = st1 - st0 + 1

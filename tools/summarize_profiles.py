@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--ny", type=int, default=4096)
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--cmd", default="")
+    ap.add_argument("--no-json", action="store_true", help="do not rewrite profiles/jacobi_pmc.json (a pass over another schedule)")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -68,6 +69,8 @@ def main():
                     hbm = (2 * v["fetch_kib"] + v["write_kib"]) * 1024
                     f.write("| %s | %.0f | %.0f | %.1f | %.2f |\n" % (k, v["fetch_kib"], v["write_kib"], hbm / 1e6,
                                                                      hbm / (a.nx * a.ny * esz)))
+        if a.no_json:
+            return
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "taichi-2d-vof_amd"))
         from vof2d._lib import kernel_source_hash
         rec = {"nx": a.nx, "ny": a.ny, "dtype": a.dtype, "tag": a.tag, "hbm_bytes_per_launch": {},
