@@ -179,7 +179,6 @@ struct vof2d_ctx {
   float tune_ms[2] = {0.f, 0.f};
   int64_t tm_steps = 0;      // steps replayed from k_tm batch graphs (counter "tm_steps")
   int tm_rows = 0;          // rows per pair chunk of k_tm (0 = 32)
-  int launch_threads = 256; // threads per block of the next launch (k_tm: 128)
   int halves = -1;   // -1: where it pays (halves_eligible), 0: never, 1: wherever the schedule allows
   std::vector<hipStream_t> chain_streams;   // streams of the chains below the first
   bool halves_captured[2] = {false, false};   // the batch graphs of size step_batch[b] the handle holds were captured in this form

@@ -110,14 +110,19 @@ const char* const kKernelNames[NKERNELS] = {"k_momentum", "k_set_bc", "k_jacobi"
 // own start/stop events (hipExtLaunchKernelGGL: the begin/end timestamps of the dispatch itself,
 // no extra barrier packets), otherwise it is a plain launch.
 template <typename... KArgs, typename... Args>
-void launch(vof2d_ctx* h, int kid, void (*kernel)(KArgs...), dim3 grid, size_t lds, Args... args) {
+void launch_block(vof2d_ctx* h, int kid, void (*kernel)(KArgs...), dim3 grid, unsigned threads, size_t lds, Args... args) {
   if (h->timed >= 0 && h->timed < vof2d_ctx::kMaxTimed) {
     const int k = h->timed++;
     h->tkid[k] = kid;
-    hipExtLaunchKernelGGL(kernel, grid, dim3(h->launch_threads), lds, h->stream, h->tev[2 * k], h->tev[2 * k + 1], 0, args...);
+    hipExtLaunchKernelGGL(kernel, grid, dim3(threads), lds, h->stream, h->tev[2 * k], h->tev[2 * k + 1], 0, args...);
   } else {
-    hipLaunchKernelGGL(kernel, grid, dim3(h->launch_threads), lds, h->stream, args...);
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, h->stream, args...);
   }
+}
+// (blocks of four waves -- four adjacent tiles -- for every kernel but k_tm, whose block is a pair of waves)
+template <typename... KArgs, typename... Args>
+void launch(vof2d_ctx* h, int kid, void (*kernel)(KArgs...), dim3 grid, size_t lds, Args... args) {
+  launch_block(h, kid, kernel, grid, 256u, lds, args...);
 }
 
 template <typename T>
@@ -339,16 +344,14 @@ struct L {
     const TbPlan tp = tb_plan(h, adapt_par);
     const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf) + (tp.masks ? 1u : 0u);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 1);
-    h->launch_threads = 128;
     if (bs)
-      launch(h, kTransport, k_tm<T, V, YFIRST, STORE_UV, true>, dim3(pairs), 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+      launch_block(h, kTransport, k_tm<T, V, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
              F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last);
     else
-      launch(h, kTransport, k_tm<T, V, YFIRST, STORE_UV, false>, dim3(pairs), 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+      launch_block(h, kTransport, k_tm<T, V, YFIRST, STORE_UV, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
              F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last);
-    h->launch_threads = 256;
   }
   // update_uv + both sweeps + post_process_f in one pass (k_transport); reads fld[fF], writes fld[fF2]
   static int transport_rows(const vof2d_ctx* h) {
