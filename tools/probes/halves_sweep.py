@@ -16,10 +16,13 @@ ap.add_argument("--steps", type=int, default=80)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--engines", type=int, default=2)
 ap.add_argument("--dt", type=float, default=0.0)
+ap.add_argument("--lib", default="", help="a variant build of the library (csrc/build/variants/...)")
 a = ap.parse_args()
+import ctypes
+from vof2d import _abi
 from vof2d._lib import hip_api
 from vof2d.engine import Engine, make_desc
-api = hip_api()
+api = _abi.bind(ctypes.CDLL(a.lib, mode=ctypes.RTLD_GLOBAL), "vof_") if a.lib else hip_api()
 engs = []
 for k in range(a.engines):
     for st in a.settings:
