@@ -154,7 +154,7 @@ struct vof2d_ctx {
   int fctx_corr_rows = 0;  // ... of its update_uv-carrying form (0 = same rule)
   int fuse_transport = 1;  // vof_step on a full domain: update_uv and both FCT sweeps in one kernel (k_transport)
   int band_rows = 4;       // rows per wave chunk of the edge-band launch of the fused transport (strips)
-  int buf_stores = 3;      // range-checked buffer stores where the grid allows (buffer_stores_ok): bit 0 k_momentum, bit 1 k_jacobi_tb
+  int buf_stores = 7;      // range-checked buffer stores where the grid allows (buffer_stores_ok): bit 0 k_momentum, bit 1 k_jacobi_tb, bit 2 k_tm's momentum wave
   int virtual_ghosts = 1;  // ... without the step's set_BC launch (k_momentum forms the ghost cells it reads)
   void* f_home = nullptr;  // the buffer fld[fF] pointed to at creation (orientation of the F / twin pair)
   int phase_graph_ori = 0; // orientation the gphase / gxchg graphs were captured in

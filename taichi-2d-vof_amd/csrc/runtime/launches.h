@@ -343,7 +343,7 @@ struct L {
     }
     const TbPlan tp = tb_plan(h, adapt_par);
     const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf) + (tp.masks ? 1u : 0u);
-    const bool bs = buffer_stores_ok(h) && (h->buf_stores & 1);
+    const bool bs = buffer_stores_ok(h) && (h->buf_stores & 4);
     if (bs)
       launch_block(h, kTransport, k_tm<T, V, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
