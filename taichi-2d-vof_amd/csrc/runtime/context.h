@@ -174,7 +174,10 @@ struct vof2d_ctx {
   int fuse_tm = -1;
   hipGraphExec_t gbatch_tm[kStepBatches][2][2] = {};   // the k_tm form of gbatch
   int tune_n = 0;            // timed batches so far (even: chains / plain, odd: k_tm); 4: ready to decide; 5: decided
-  int tm_choice = 0;         // the form that stays
+  int tm_choice = 0;         // the form that stays -- until the next timing: every tune_period batches the two forms are timed
+  int tune_period = 2048;    // again (a flow changes character over 16 000 steps; four alternating batches cost next to nothing)
+  int tune_age = 0;          // batches since the last decision
+  bool tm_decided = false;   // a decision has been made since the graphs were built
   hipEvent_t tune_ev[8] = {};
   float tune_ms[2] = {0.f, 0.f};
   int64_t tm_steps = 0;      // steps replayed from k_tm batch graphs (counter "tm_steps")

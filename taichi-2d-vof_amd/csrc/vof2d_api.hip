@@ -324,11 +324,18 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
           }
           h->tm_choice = (done && h->tune_ms[1] < 0.99f * h->tune_ms[0]) ? 1 : 0;
           h->tune_n = 5;
+          h->tm_decided = true;
           if (!done) (void)hipGetLastError();
           if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] batch forms timed: %.3f ms (chains / plain) vs %.3f ms (k_tm) per 16 steps -> %s\n", h->tune_ms[0], h->tune_ms[1], h->tm_choice ? "k_tm" : "chains / plain");
         }
-        if (h->tune_n < 4) { variant = h->tune_n & 1; timed = nsteps - s >= h->step_batch[0]; if (!timed) variant = 0; }
-        else variant = h->tm_choice;
+        if (h->tune_n == 5 && h->tune_period > 0 && h->tune_age >= h->tune_period) {   // time the forms again
+          h->tune_n = 0; h->tune_age = 0; h->tune_ms[0] = h->tune_ms[1] = 0.f;
+        }
+        if (h->tune_n < 4) {
+          timed = nsteps - s >= h->step_batch[0];
+          variant = timed ? (h->tune_n & 1) : (h->tm_decided ? h->tm_choice : 0);
+        }
+        else { variant = h->tm_choice; h->tune_age += 1; }
       }
       auto& GB = variant ? h->gbatch_tm : h->gbatch;
       if (h->batching && !GB[0][par][h->fld[fF] == h->f_home ? 0 : 1]) build_step_batches(h, variant);
@@ -657,7 +664,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
             : !strcmp(name, "momentum_rows") ? &h->mom_rows : !strcmp(name, "fctx_rows") ? &h->fctx_rows
             : !strcmp(name, "fctx_corr_rows") ? &h->fctx_corr_rows : !strcmp(name, "band_rows") ? &h->band_rows
             : !strcmp(name, "rows_per_wave") ? &h->rows_override : !strcmp(name, "fuse_transport") ? &h->fuse_transport
-            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : nullptr;
+            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : !strcmp(name, "tune_period") ? &h->tune_period : nullptr;
   if (knob) {
     *knob = (int)value;
     if (knob == &h->band_rows && *knob < 1) *knob = 1;
@@ -709,7 +716,7 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
     return VOF_OK;
   }
   if (!strcmp(name, "tm_choice")) {   // -1: the forms are still being timed (or never will be), 0 / 1: the form that stayed
-    *value = (tm_auto(h) && h->tune_n == 5) ? h->tm_choice : -1;
+    *value = (tm_auto(h) && h->tm_decided) ? h->tm_choice : -1;
     return VOF_OK;
   }
   if (!strcmp(name, "halves_steps")) {   // steps replayed from batch graphs in the two-chain form (enqueue_steps_halves)

@@ -126,3 +126,26 @@ def test_strips_inside_the_front(hip_api, nstrips):
     assert full.get_counter("tb_plan_active") == 1
     assert sum(1 for x in planned if x > 10) >= nstrips // 2, planned     # most strips met the front and planned
     assert sum(s.get_counter("courant_violations") for s in strips) == full.get_counter("courant_violations")
+
+
+def test_batch_forms_are_timed_again_and_switching_changes_no_value(hip_api):
+    """fuse_tm = -1 (the default) on a large fp64 grid: the handle alternates its two batch forms over four 8-step
+    batches, keeps the faster, and does so again every `tune_period` batches.  With a period of 5 batches a run of 250
+    steps goes through the timing three to four times: both forms run for dozens of steps each, in turns -- and the state
+    equals the plain four-kernel sequence's value for value (4096^2 dam-break, the headline configuration)."""
+    n = 4096
+    a = engine(hip_api, n, n, "f64", "f32", ic=1)
+    a.set_param("tune_period", 5)
+    b = engine(hip_api, n, n, "f64", "f32", ic=1)
+    b.set_param("overlap_halves", 0)
+    b.set_param("fuse_tm", 0)
+    for st in (90, 250):
+        a.step(st - a.istep)
+        b.step(st - b.istep)
+        for f in STATE:
+            x, y = a.get(f), b.get(f)
+            assert same(x, y), "step %d: %s" % (st, diff_report(x, y, f))
+            del x, y
+    tm, ch = a.get_counter("tm_steps"), a.get_counter("halves_steps")
+    assert tm >= 3 * 16 and ch >= 3 * 16 and tm + ch >= 230, (tm, ch)
+    assert a.get_counter("tm_choice") in (0, 1) and b.get_counter("tm_steps") + b.get_counter("halves_steps") == 0
