@@ -820,3 +820,27 @@ def test_fused_transport_momentum_changes_no_value(hip_api, oracle_api, dtype, i
     assert a.get_counter("courant_violations") == o.get_counter("courant_violations")
     if ring:
         assert planned >= 2, planned
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ic,nx,ny", [("f64", 1, 2048, 2048), ("f64", 2, 1536, 3000), ("f32", 3, 2048, 2048)])
+def test_fused_transport_momentum_mid_size_twice(hip_api, dtype, ic, nx, ny):
+    """k_tm on grids of a few million cells, twice, against the plain sequence.  The store-data hazard of round 4 (a
+    16-byte buffer store with an SGPR soffset whose data registers the next VALU instruction overwrote: k_tm's rhs
+    held v* values in some lanes) showed only from about 1024^2 up and not in every run; the small-grid cases of
+    test_fused_transport_momentum_changes_no_value never saw it."""
+    b = engine(hip_api, nx, ny, dtype, "f32", ic=ic)
+    b.set_param("overlap_halves", 0)
+    b.set_param("fuse_tm", 0)
+    b.step(27)
+    ref = {f: b.get(f) for f in STATE + ("u_star", "v_star", "rhs")}
+    for rep in range(2):
+        a = engine(hip_api, nx, ny, dtype, "f32", ic=ic)
+        a.set_param("overlap_halves", 0)
+        a.set_param("fuse_tm", 1)
+        a.step(27)
+        for f, y in ref.items():
+            x = a.get(f)
+            assert same(x, y), "run %d: %s" % (rep, diff_report(x, y, f))
+        assert a.get_counter("tm_steps") >= 24
+        a.close()
