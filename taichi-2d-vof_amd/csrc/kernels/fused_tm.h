@@ -20,6 +20,9 @@
 //   * u*', v*' go to a second pair of arrays (chunks of other workgroups still read the old u*, v*); the caller
 //     alternates the pairs.
 // Full domains, virtual ghosts (the steady-state fused step) only.
+// The two marches below are k_transport's and k_momentum's row loops with the source / sink of F'', u, v exchanged (LDS
+// instead of memory) and the chunk bounds of the pair; they are kept as copies, not shared with the stand-alone kernels,
+// so that those kernels' register allocation and instruction schedule stay what profiles/ measured.
 #pragma once
 #include "momentum.h"
 #include "transport.h"

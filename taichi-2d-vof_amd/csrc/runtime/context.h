@@ -167,7 +167,7 @@ struct vof2d_ctx {
   hipGraphExec_t gbatch[kStepBatches][2][2] = {};   // [batch size][parity of the first step][orientation]
   // knob "overlap_halves": the batch graphs run every kernel of a step as two launches, on the rows above and below a
   // boundary that moves up by kHalvesDrift rows from kernel to kernel, the upper chain on `stream`, the lower on
-  // `stream2`; a lower launch waits for the upper launch of the kernel before it only (enqueue_steps_halves)
+  // `chain_streams`; a lower launch waits for the upper launch of the kernel before it only (enqueue_steps_halves)
   // knob "fuse_tm": the batch graphs run k_transport + the next step's k_momentum as one kernel (k_tm, kernels/fused_tm.h):
   // 0 never, 1 wherever the schedule allows, -1 (default) on large fp64 grids after timing both forms on the handle's
   // own data: four 8-step batches alternate between the forms, the faster one stays (vof_step)
