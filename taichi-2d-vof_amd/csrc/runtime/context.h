@@ -172,6 +172,11 @@ struct vof2d_ctx {
   // 0 never, 1 wherever the schedule allows, -1 (default) on large fp64 grids after timing both forms on the handle's
   // own data: four 8-step batches alternate between the forms, the faster one stays (vof_step)
   int fuse_tm = -1;
+  int jpair = 1;             // knob "jacobi_pair": the k_tm batch graphs run each two five-sweep launches as one k_jacobi_pair launch
+  int jpair_rows = 0;        // rows per pair chunk (0 = one residency round of pairs)
+  bool jpair_active = false; // the launches being enqueued are k_jacobi_pair's (tb_plan describes their geometry)
+  bool jpair_captured = false;   // the k_tm batch graphs the handle holds contain k_jacobi_pair launches
+  int64_t pair_launches = 0; // k_jacobi_pair launches replayed (counter "pair_launches")
   hipGraphExec_t gbatch_tm[kStepBatches][2][2] = {};   // the k_tm form of gbatch
   int tune_n = 0;            // timed batches so far (even: chains / plain, odd: k_tm); 4: ready to decide; 5: decided
   int tm_choice = 0;         // the form that stays -- until the next timing: every tune_period batches the two forms are timed

@@ -21,6 +21,26 @@ namespace {
 // Used for the two register-heavy, long-lived-wave kernels (k_jacobi_tb: -15 us per step at
 // 4096^2, k_momentum: -3 us); the HBM-bound kernels with short-lived waves measured best with the
 // plain cells-per-wave rule (chunk_rows) and keep it.
+// (blocks of `threads` threads that fit the chip at once)
+template <typename K>
+long resident_blocks(vof2d_ctx* h, K kernel, int threads) {
+  std::map<const void*, long>& cache = h->occ_cache;
+  const void* key = reinterpret_cast<const void*>(kernel);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int blocks_per_cu = 0;
+  long cap = 6L * 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, threads, 0) == hipSuccess && blocks_per_cu > 0) {
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    cap = (long)blocks_per_cu * cus;
+  } else {
+    (void)hipGetLastError();
+  }
+  cache[key] = cap;
+  return cap;
+}
 template <typename K>
 long resident_waves(vof2d_ctx* h, K kernel) {
   std::map<const void*, long>& cache = h->occ_cache;  // per handle (one host thread per handle)
@@ -219,6 +239,33 @@ struct L {
     const long cap = sq ? resident_waves(h, k_jacobi_tb<T, VV, TS, true, false>) : resident_waves(h, k_jacobi_tb<T, VV, TS, false, false>);
     return h->tb_rows > 0 ? h->tb_rows : chunk_rows_fit(h, ntt, cap, 4, 96);
   }
+  // k_jacobi_pair (two five-sweep launches as one, kernels/jacobi_pair.h): square cells, ten sweeps per step at least
+  static bool jacobi_pair_ok(vof2d_ctx* h) {
+    const Consts<T> cc = C(h);
+    return h->jpair > 0 && cc.dxi2 == cc.dyi2 && !h->tb_general && h->tb >= 5 && h->d.jacobi_iters % 10 == 0;
+  }
+  static int jacobi_pair_geom(vof2d_ctx* h, int& ntt) {
+    constexpr int ST = 64 * V - 2 * 2 * (((5 - 1 + 1 + V - 1) / V) * V);   // must match the kernel: 104 columns
+    ntt = (h->g.ny + ST - 1) / ST;
+    const bool bs = buffer_stores_ok(h) && (h->buf_stores & 2);
+    const long cap = bs ? resident_blocks(h, k_jacobi_pair<T, V, 5, true>, 128) : resident_blocks(h, k_jacobi_pair<T, V, 5, false>, 128);
+    return h->jpair_rows > 0 ? h->jpair_rows : chunk_rows_fit(h, ntt, cap, 8, 160);
+  }
+  // ten sweeps src -> dst
+  static void jacobi_pair(vof2d_ctx* h, int src, int dst, int adapt_par = -1, int first = 1, int last = 0) {
+    if (last < first) { first = h->g.ilo; last = h->g.ihi; }
+    int ntt = 0;
+    const int R = jacobi_pair_geom(h, ntt);
+    const TbPlan tp = tb_plan(h, adapt_par);
+    const unsigned pairs = tp.masks ? (unsigned)tp.waves : (unsigned)(((last - first + R) / R) * ntt);
+    const bool bs = buffer_stores_ok(h) && (h->buf_stores & 2);
+    if (bs)
+      launch_block(h, kJacobiTB, k_jacobi_pair<T, V, 5, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
+                   (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last);
+    else
+      launch_block(h, kJacobiTB, k_jacobi_pair<T, V, 5, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
+                   (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last);
+  }
   // the work plan of the step's five-sweep launches (see tb_make_plan): active on parity-keyed step
   // sequences (adapt_par = istep & 1), square or not, two columns per lane, up to TB_COLS tile columns
   static TbPlan tb_plan(vof2d_ctx* h, int adapt_par) {
@@ -227,8 +274,15 @@ struct L {
     const Consts<T> cc = C(h);
     const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;
     int ntt = 0;
-    const int R = jacobi_tb_plan<5, V>(h, sq, ntt);
-    const long waves = (long)blocks_for(h, ntt, R) * 4;
+    int R;
+    long waves;
+    if (h->jpair_active) {   // the step's Jacobi launches are k_jacobi_pair's: the plan's "waves" are pairs on 104-column tiles
+      R = jacobi_pair_geom(h, ntt);
+      waves = (long)((h->g.ihi - h->g.ilo + R) / R) * ntt;
+    } else {
+      R = jacobi_tb_plan<5, V>(h, sq, ntt);
+      waves = (long)blocks_for(h, ntt, R) * 4;
+    }
     if (ntt > TB_COLS || waves > kTbPlanWaves) return tp;
     tp.masks = h->d_tbmask;
     tp.plan = h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64);

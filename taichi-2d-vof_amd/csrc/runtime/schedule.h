@@ -289,19 +289,36 @@ bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
 // launches and k_tm (this step's transport + the next step's momentum), the last step ending in a plain k_transport
 // that stores u and v.  u*, v* alternate between their own arrays and the (otherwise verb-only) mx, my arrays; the
 // first k_momentum writes whichever pair makes the last step's land in their own.
+inline void swap_P(vof2d_ctx* h) { void* t = h->fld[fP]; h->fld[fP] = h->fld[fPT]; h->fld[fPT] = t; }
+// the step's Jacobi sweeps inside a batch: pairs of five-sweep launches as k_jacobi_pair where the handle allows (each
+// leaves its result in the other array of the p / pt pair: the host's view is swapped along, an even number of times
+// per batch of an even number of steps), else k_jacobi_tb launches ending in fld[fP]
+template <typename T>
+void batch_jacobi(vof2d_ctx* h, int par) {
+  const int nj = h->d.jacobi_iters / 5;
+  if (L<T>::jacobi_pair_ok(h)) {
+    for (int j = 0; j < nj / 2; ++j) {
+      L<T>::jacobi_pair(h, fP, fPT, par);
+      swap_P(h);
+    }
+    return;
+  }
+  int cur = fP, oth = fPT;
+  for (int j = 0; j < nj; ++j) {
+    L<T>::template jacobi_tb<5>(h, cur, oth, par);
+    const int t = cur; cur = oth; oth = t;
+  }
+}
 template <typename T>
 void enqueue_steps_tm(vof2d_ctx* h, int64_t first_step, int K) {
-  const int nj = h->d.jacobi_iters / 5;
+  h->jpair_active = L<T>::jacobi_pair_ok(h);
+  h->jpair_captured = h->jpair_active;
   if ((K - 1) & 1) swap_S(h);
   L<T>::momentum(h, true, (int)(first_step & 1));
   for (int k = 0; k < K; ++k) {
     const int64_t istep = first_step + k;
     const int par = (int)(istep & 1);
-    int cur = fP, oth = fPT;
-    for (int j = 0; j < nj; ++j) {
-      L<T>::template jacobi_tb<5>(h, cur, oth, par);
-      const int t = cur; cur = oth; oth = t;
-    }
+    batch_jacobi<T>(h, par);
     if (k < K - 1) {
       if (istep % 2 == 0) L<T>::template tm<true, false>(h, par ^ 1); else L<T>::template tm<false, false>(h, par ^ 1);
       swap_S(h);
@@ -310,6 +327,8 @@ void enqueue_steps_tm(vof2d_ctx* h, int64_t first_step, int K) {
     }
     swap_F(h);
   }
+  if (h->jpair_active && ((K * (h->d.jacobi_iters / 10)) & 1)) swap_P(h);   // (never: K is even)
+  h->jpair_active = false;
   // (the first swap and the K - 1 in the loop are an even number: the host's view of the pairs is back where it was)
 }
 

@@ -357,7 +357,7 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
         }
         h->istep += K - 1;
         s += K - 1;
-        if (variant) h->tm_steps += K;
+        if (variant) { h->tm_steps += K; if (h->jpair_captured) h->pair_launches += (int64_t)K * (h->d.jacobi_iters / 10); }
         else if (h->halves_captured[b]) h->halves_steps += K;
         batched = true;
       }
@@ -664,7 +664,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
             : !strcmp(name, "momentum_rows") ? &h->mom_rows : !strcmp(name, "fctx_rows") ? &h->fctx_rows
             : !strcmp(name, "fctx_corr_rows") ? &h->fctx_corr_rows : !strcmp(name, "band_rows") ? &h->band_rows
             : !strcmp(name, "rows_per_wave") ? &h->rows_override : !strcmp(name, "fuse_transport") ? &h->fuse_transport
-            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : !strcmp(name, "tune_period") ? &h->tune_period : nullptr;
+            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : !strcmp(name, "jacobi_pair") ? &h->jpair : !strcmp(name, "jacobi_pair_rows") ? &h->jpair_rows : !strcmp(name, "tune_period") ? &h->tune_period : nullptr;
   if (knob) {
     *knob = (int)value;
     if (knob == &h->band_rows && *knob < 1) *knob = 1;
@@ -709,6 +709,10 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
     HIPCHK(h, hipMemcpyAsync(&v, h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64), sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *value = (int64_t)v;
+    return VOF_OK;
+  }
+  if (!strcmp(name, "pair_launches")) {   // k_jacobi_pair launches replayed from batch graphs
+    *value = h->pair_launches;
     return VOF_OK;
   }
   if (!strcmp(name, "tm_steps")) {   // steps replayed from batch graphs in the k_tm form

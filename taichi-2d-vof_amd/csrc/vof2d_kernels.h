@@ -14,6 +14,7 @@
 //   plan.h       the equal-cost work plan of the fused Jacobi launches
 //   momentum.h   k_momentum      (cal_nu_rho + get_normal_young + advect_upwind + rhs)
 //   jacobi.h     k_jacobi, k_jacobi_tb   (solve_p_jacobi, the north-star kernel)
+//   jacobi_pair.h  k_jacobi_pair   (two k_jacobi_tb launches as one: pairs of waves, result and rhs rows through LDS)
 //   transport.h  k_fct_x, k_fct_y, k_transport   (update_uv + solve_VOF_rudman + post_process_f)
 //   fused_tm.h   k_tm   (k_transport of one step + k_momentum of the next, rows handed over through LDS)
 #pragma once
@@ -22,5 +23,6 @@
 #include "kernels/plan.h"
 #include "kernels/momentum.h"
 #include "kernels/jacobi.h"
+#include "kernels/jacobi_pair.h"
 #include "kernels/transport.h"
 #include "kernels/fused_tm.h"

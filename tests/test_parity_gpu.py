@@ -844,3 +844,46 @@ def test_fused_transport_momentum_mid_size_twice(hip_api, dtype, ic, nx, ny):
             assert same(x, y), "run %d: %s" % (rep, diff_report(x, y, f))
         assert a.get_counter("tm_steps") >= 24
         a.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ic,n,ring,rows", [("f64", 1, 512, False, 0), ("f32", 2, 640, False, 0), ("f64", 3, 448, True, 0), ("f32", 1, 600, True, 48),
+                                                ("f64", 1, 300, True, 33)])
+def test_jacobi_pair_changes_no_value(hip_api, oracle_api, dtype, ic, n, ring, rows):
+    """k_jacobi_pair (kernels/jacobi_pair.h): each two five-sweep launches of a step as ONE launch -- a workgroup is a pair
+    of waves on one tile, the first wave's result rows and the rhs rows it loaded handed to the second through rings in
+    LDS.  Runs in the k_tm batch graphs on square cells (forced here on small square grids), against the plain sequence
+    and the oracle; `ring`: tiny pressure values, so that the pairs run the equal-cost work plan (planned by the
+    k_momentum / k_tm planner block on the pairs' own geometry); ragged and forced chunk lengths."""
+    kw = {"gy": 0.0} if ring else {}
+    a = engine(hip_api, n, n, dtype, "f32", ic=ic, **kw)
+    a.set_param("overlap_halves", 0)
+    a.set_param("fuse_tm", 1)
+    a.set_param("jacobi_pair", 1)
+    a.set_param("jacobi_pair_rows", rows)
+    b = engine(hip_api, n, n, dtype, "f32", ic=ic, **kw)
+    b.set_param("overlap_halves", 0)
+    b.set_param("fuse_tm", 0)
+    o = engine(oracle_api, n, n, dtype, "f32", ic=ic, **kw)
+    assert a.get_param("dx") == a.get_param("dy")          # (square cells: the pair kernel is in use)
+    if ring:
+        tiny = 1e-290 if dtype == "f64" else 1e-32
+        rng = np.random.default_rng(n)
+        p0 = np.zeros((n + 2, n + 2))
+        i, j = np.meshgrid(np.arange(n + 2), np.arange(n + 2), indexing="ij")
+        r = np.hypot(i - 0.5 * n, j - 0.4 * n)
+        band = (r > 0.2 * n) & (r < 0.4 * n)
+        p0[band] = tiny * rng.uniform(0.5, 2.0, size=int(band.sum()))
+        p0[r <= 0.2 * n] = 1.0
+        for e in (a, b, o):
+            e.set("p", p0)
+    planned = 0
+    for st in (1, 3, 11, 12, 22, 23, 40):
+        for e in (a, b, o):
+            e.step(st - e.istep)
+        planned += a.get_counter("tb_plan_active")
+        assert_fields_same(a, b, STATE + ("u_star", "v_star", "rhs"), ctx="pair on / off, %s %d^2 step %d" % (dtype, n, st))
+        assert_fields_same(a, o, ctx="pair / oracle, %s %d^2 step %d" % (dtype, n, st))
+    assert a.get_counter("tm_steps") == 36 and a.get_counter("pair_launches") == 36
+    if ring:
+        assert planned >= 2, planned
