@@ -242,7 +242,10 @@ struct L {
   // k_jacobi_pair (two five-sweep launches as one, kernels/jacobi_pair.h): square cells, ten sweeps per step at least
   static bool jacobi_pair_ok(vof2d_ctx* h) {
     const Consts<T> cc = C(h);
-    return h->jpair > 0 && cc.dxi2 == cc.dyi2 && !h->tb_general && h->tb >= 5 && h->d.jacobi_iters % 10 == 0;
+    // (fp32: slower than two k_jacobi_tb launches -- 4096^2 k_tm form 0.3615 -> 0.3815 ms/step: those are issue-bound and the
+    // pairs add a fifth of redundant stage-rows; knob value 2 forces the pairs there too, for the tests)
+    return (h->jpair > 1 || (h->jpair == 1 && sizeof(T) == 8)) && cc.dxi2 == cc.dyi2 && !h->tb_general && h->tb >= 5 &&
+           h->d.jacobi_iters % 10 == 0;
   }
   static int jacobi_pair_geom(vof2d_ctx* h, int& ntt) {
     constexpr int ST = 64 * V - 2 * 2 * (((5 - 1 + 1 + V - 1) / V) * V);   // must match the kernel: 104 columns
