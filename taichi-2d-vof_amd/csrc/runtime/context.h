@@ -162,8 +162,11 @@ struct vof2d_ctx {
   // several consecutive steady-state steps of a full domain as ONE graph (step_batch[b] steps, an even number: the
   // F / twin pair and the step parity are back where they started): a graph launch leaves ~9 us of idle queue
   // behind it, which one launch per step pays every step (vof_step)
-  static constexpr int kStepBatches = 2;
-  int step_batch[kStepBatches] = {8, 2};   // (32 measured no better than 8; knob "batch_steps" sets the first)
+  static constexpr int kStepBatches = 3;
+  static constexpr int kTuneBatch = 1;     // the batch size the two forms are timed with (fuse_tm = -1)
+  // (the k_tm form has one plain k_momentum and one plain k_transport per batch: 4096^2 0.5256 ms/step in batches of 8, 0.5193 of 16,
+  // 0.5178 of 32, 0.5346 of 4; knob "batch_steps" sets the first)
+  int step_batch[kStepBatches] = {16, 8, 2};
   hipGraphExec_t gbatch[kStepBatches][2][2] = {};   // [batch size][parity of the first step][orientation]
   // knob "overlap_halves": the batch graphs run every kernel of a step as two launches, on the rows above and below a
   // boundary that moves up by kHalvesDrift rows from kernel to kernel, the upper chain on `stream`, the lower on
@@ -189,7 +192,7 @@ struct vof2d_ctx {
   int tm_rows = 0;          // rows per pair chunk of k_tm (0 = 32)
   int halves = -1;   // -1: where it pays (halves_eligible), 0: never, 1: wherever the schedule allows
   std::vector<hipStream_t> chain_streams;   // streams of the chains below the first
-  bool halves_captured[2] = {false, false};   // the batch graphs of size step_batch[b] the handle holds were captured in this form
+  bool halves_captured[kStepBatches] = {};   // the batch graphs of size step_batch[b] the handle holds were captured in this form
   int64_t halves_steps = 0;       // steps replayed from them (counter "halves_steps")
   std::vector<hipEvent_t> hev;
   bool batching = true;         // false after a failed capture of a batch: one graph launch per step from then on (build_step_batches)

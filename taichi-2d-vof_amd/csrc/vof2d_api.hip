@@ -332,7 +332,7 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
           h->tune_n = 0; h->tune_age = 0; h->tune_ms[0] = h->tune_ms[1] = 0.f;
         }
         if (h->tune_n < 4) {
-          timed = nsteps - s >= h->step_batch[0];
+          timed = nsteps - s >= h->step_batch[vof2d_ctx::kTuneBatch];
           variant = timed ? (h->tune_n & 1) : (h->tm_decided ? h->tm_choice : 0);
         }
         else { variant = h->tm_choice; h->tune_age += 1; }
@@ -341,10 +341,10 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       if (h->batching && !GB[0][par][h->fld[fF] == h->f_home ? 0 : 1]) build_step_batches(h, variant);
       const int ori = h->fld[fF] == h->f_home ? 0 : 1;
       bool batched = false;
-      for (int b = 0; b < vof2d_ctx::kStepBatches && !batched; ++b) {
+      for (int b = timed ? vof2d_ctx::kTuneBatch : 0; b < vof2d_ctx::kStepBatches && !batched; ++b) {   // (while the forms are being timed: batches of the timed size)
         const int K = h->step_batch[b];
         if (nsteps - s < K || !GB[b][par][ori]) continue;
-        const bool time_it = timed && b == 0 && h->batching;
+        const bool time_it = timed && b == vof2d_ctx::kTuneBatch && h->batching;
         if (time_it) {
           for (int k = 0; k < 2; ++k)
             if (!h->tune_ev[2 * h->tune_n + k] && hipEventCreate(&h->tune_ev[2 * h->tune_n + k]) != hipSuccess) return fail(h, VOF_EHIP, "hipEventCreate");
@@ -688,7 +688,7 @@ int vof_get_param(vof2d_handle h, const char* name, double* value) {
   if (!strcmp(name, "rows_per_wave")) { *value = (double)pick_rows(h, h->g.ntj); return VOF_OK; }
   if (!strcmp(name, "jacobi_tb")) { *value = (double)h->tb; return VOF_OK; }
   if (!strcmp(name, "jacobi_tb_adapt")) { *value = (double)h->tb_adapt; return VOF_OK; }
-  if (!strcmp(name, "overlap_halves")) { *value = halves_eligible(h, h->step_batch[0]) ? 1.0 : 0.0; return VOF_OK; }   // effective
+  if (!strcmp(name, "overlap_halves")) { *value = halves_eligible(h, h->step_batch[vof2d_ctx::kTuneBatch]) ? 1.0 : 0.0; return VOF_OK; }   // effective
   if (!strcmp(name, "fuse_transport")) {  // 1 if vof_step runs both FCT sweeps as one kernel on this handle
     *value = (h->g.wall_lo && h->g.wall_hi && h->fuse_transport) ? 1.0 : 0.0;
     return VOF_OK;

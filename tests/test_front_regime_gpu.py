@@ -130,12 +130,12 @@ def test_strips_inside_the_front(hip_api, nstrips):
 
 def test_batch_forms_are_timed_again_and_switching_changes_no_value(hip_api):
     """fuse_tm = -1 (the default) on a large fp64 grid: the handle alternates its two batch forms over four 8-step
-    batches, keeps the faster, and does so again every `tune_period` batches.  With a period of 5 batches a run of 250
+    batches, keeps the faster, and does so again every `tune_period` batches.  With a period of 2 batches (of 16 steps) a run of 250
     steps goes through the timing three to four times: both forms run for dozens of steps each, in turns -- and the state
     equals the plain four-kernel sequence's value for value (4096^2 dam-break, the headline configuration)."""
     n = 4096
     a = engine(hip_api, n, n, "f64", "f32", ic=1)
-    a.set_param("tune_period", 5)
+    a.set_param("tune_period", 2)
     b = engine(hip_api, n, n, "f64", "f32", ic=1)
     b.set_param("overlap_halves", 0)
     b.set_param("fuse_tm", 0)

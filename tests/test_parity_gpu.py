@@ -724,6 +724,7 @@ def test_overlap_halves_change_no_value(hip_api, oracle_api, dtype, ic, nx, ny, 
     kw = {"gy": 0.0} if ring else {}
     a = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
     a.set_param("fuse_tm", 0)
+    a.set_param("batch_steps", 8)                 # (batches of 16 want at least 640 rows per pair of chains)
     a.set_param("overlap_halves", chains)         # (odd ny: the exec-masked store forms; 3 / 4 chains: every middle chain has two moving boundaries)
     b = engine(hip_api, nx, ny, dtype, "f32", ic=ic, **kw)
     b.set_param("overlap_halves", 0)
@@ -764,6 +765,7 @@ def test_warm_handle_reset_to_the_initial_state_repeats_the_run(hip_api, dtype, 
     warm = engine(hip_api, nx, ny, dtype, "f32", ic=1)
     warm.set_param("overlap_halves", 1)
     warm.set_param("fuse_tm", 0)
+    warm.set_param("batch_steps", 8)
     warm.step(13)
     zeros = np.zeros((nx + 2, ny + 2))
     for f in ("F", "u", "v", "p"):
