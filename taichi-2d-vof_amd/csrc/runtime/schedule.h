@@ -201,7 +201,7 @@ inline bool tm_eligible(const vof2d_ctx* h) {
 // rising bubble 0.682 / 0.612 / 0.808 -- mostly liquid: the pair is bound by its instruction issue --, 4096^2 fp32
 // 0.364 / 0.337 / 0.361, 3072^2 0.351 / 0.346 / 0.346, 2048^2 0.168 / - / 0.188)
 inline bool tm_auto(const vof2d_ctx* h) {
-  return h->fuse_tm < 0 && tm_eligible(h) && h->d.dtype == VOF_F64 && (long)h->g.nx * h->g.ny >= 12000000L && h->g.nx >= 2048;
+  return h->fuse_tm < 0 && tm_eligible(h) && h->d.dtype == VOF_F64 && (long)h->g.nx * h->g.ny >= 6000000L && h->g.nx >= 2048;   // (the sizes that run chains: below, neither form pays)
 }
 // chains: two; three from 32 M cells (8192^2: 2.30 ms/step in one chain, 2.29 in two, 2.16 in three, 2.17 in four; 4096^2: 0.595 / 0.574 /
 // 0.566 / 0.579 inside the front, 0.582 / 0.562 / 0.565 / 0.583 behind it); knob values >= 2 force a count
