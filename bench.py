@@ -32,7 +32,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 ARRAYS_PER_STEP_FULL = 19
 ARRAYS_PER_STEP_STRIP = 22
 # algorithmic array passes per launch of the kernels of the fused step (same counting rule)
-KERNEL_PASSES = {"k_momentum": 6, "k_jacobi_tb": 3, "k_transport": 7, "k_jacobi": 3, "k_fct_x": 7, "k_fct_y": 7}
+KERNEL_PASSES = {"k_momentum": 6, "k_jacobi_tb": 3, "k_transport": 7, "k_jacobi": 3, "k_fct_x": 7, "k_fct_y": 7,
+                 # k_tm (k_transport + the next step's k_momentum): F, u*, v*, p -> F'', u*', v*', rhs'; k_jacobi_pair: p, rhs -> p after TEN sweeps
+                 "k_tm": 8, "k_jacobi_pair": 3}
 
 
 def parse():
@@ -476,6 +478,34 @@ def roofline_record(step_kernels, traffic, traffic_note, nprof, prof_note, sweep
             "in_step_lowest": low, "north_star_single_sweep": single}
 
 
+def roofline_of_the_kept_form(run_kernels, classic, traffic_tm, note_tm, nprof, esz, cells):
+    """`roofline` when the handle keeps the k_tm form (large fp64 grids): the step is k_jacobi_pair
+    (two five-sweep launches as one) and k_tm (k_transport + the next step's k_momentum as one), and k_tm is the
+    dominant kernel -- about two thirds of the step.  Algorithmic bytes by SURVEY 8d's rule (every distinct array a
+    kernel reads or writes, once): 8 passes for k_tm, 3 for k_jacobi_pair's ten sweeps.  The rule counts what a
+    kernel has to move, so a kernel that fuses more has fewer bytes to show for its time: next to `frac` stand the
+    bytes of the kernels it replaces, and the whole step on the reference's 19 passes is `step_frac_of_peak_algorithmic`.
+    `one_kernel_at_a_time` is the record of the four classic kernels (k_jacobi_tb: the previous rounds' `roofline`)."""
+    tm = run_kernels["k_tm"]
+    us = tm["us_per_launch_dispatch"]
+    per_step = sum(v["us_per_launch_dispatch"] * v["launches_per_step"] for v in run_kernels.values())
+    out = {"bound": "hbm", "kernel": "k_tm", "achieved": tm["frac_of_peak"] * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": tm["frac_of_peak"], "traffic": traffic_tm.get("tm"), "traffic_note": note_tm, "us_per_launch": us,
+           "algorithmic_passes": 8, "algorithmic_bytes_per_launch": tm["algorithmic_bytes_per_launch"],
+           "share_of_the_step_kernel_time": us * tm["launches_per_step"] / per_step if per_step else None,
+           "frac_on_the_bytes_of_the_two_kernels_it_replaces": (7 + 6) * esz * cells / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "duration_source": "in-situ profile (vof_profile_steps) of the launch sequence the handle's batch graphs replay, every launch "
+                              "between its own HIP event pair, %d steps from step 11 of a run on the warmed handle" % nprof,
+           "step_kernels_as_run": run_kernels, "one_kernel_at_a_time": classic,
+           "north_star_single_sweep": classic.get("north_star_single_sweep")}
+    jp = run_kernels.get("k_jacobi_pair")
+    if jp:
+        out["jacobi_kernel_of_the_step"] = dict(jp, kernel="k_jacobi_pair", sweeps_per_launch=10, traffic=traffic_tm.get("pair"),
+                                                sweeps_GBs_by_the_24B_rule=10 * 3 * esz * cells / (jp["us_per_launch_dispatch"] * 1e-6) / 1e9,
+                                                frac_on_the_bytes_of_the_two_launches_it_replaces=2 * jp["frac_of_peak"])
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 def main():
     a = parse()
@@ -701,6 +731,7 @@ def main():
     # regime in which the tiny-value front of the pressure iteration crosses the grid.  (`eng` has just had its p
     # advanced by the back-to-back Jacobi launches above, which is not a state the solver passes through.)
     prof, prof_note, nprof = {}, None, max(1, a.profile_steps)
+    prof_run = {}
     if not dist_path:
         try:
             from vof2d.engine import Engine as _E, make_desc as _md
@@ -709,6 +740,11 @@ def main():
                 e1.set_init_F(a.ic)
                 e1.step(10)
                 prof = e1.profile_steps(nprof)
+                # ... and the launches of the form the handle keeps (k_tm / k_jacobi_pair on a large fp64 grid), the same
+                # steps of the same run: the handle is warmed (which decides the form) and put back to the initial state
+                warm_handle(e1, a.ic, nx, ny, a.dtype)
+                e1.step(10)
+                prof_run = e1.profile_steps(nprof) if e1.get_counter("tm_choice") == 1 else {}
             finally:
                 e1.close()
         except Exception as exc:      # e.g. not enough free HBM for a second engine: the line survives without the breakdown
@@ -719,6 +755,11 @@ def main():
                         "algorithmic_bytes_per_launch": KERNEL_PASSES[k] * esz * cells, "us_per_launch_dispatch": round(v[0], 2),
                         "frac_of_peak": KERNEL_PASSES[k] * esz * cells / (v[0] * 1e-6) / 1e9 / HBM_PEAK_GBS}
                     for k, v in prof.items() if k in KERNEL_PASSES and v[0] > 0}
+
+    run_kernels = {k: {"launches_per_step": round(v[1] / float(nprof), 3), "algorithmic_passes": KERNEL_PASSES[k],
+                       "algorithmic_bytes_per_launch": KERNEL_PASSES[k] * esz * cells, "us_per_launch_dispatch": round(v[0], 2),
+                       "frac_of_peak": KERNEL_PASSES[k] * esz * cells / (v[0] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                   for k, v in prof_run.items() if k in KERNEL_PASSES and v[0] > 0}
 
     # which schedule actually ran: the 19-pass one-kernel transport needs a full domain, or mode 4 with
     # EVERY timed step replayed from the captured exchange graph (an RCCL that cannot capture, or
@@ -786,6 +827,7 @@ def main():
                 "note": "one sweep per launch, back-to-back launches between one HIP event pair (vof_time_jacobi); used by "
                         "the step only for sweep counts that are not a multiple of five and for the residual checks"}),
             "jacobi_fused": fused,
+            "step_kernels_as_run": run_kernels or None,
             # the kernels the step itself runs, same counting rule (built-in profiler: dispatch start ->
             # stop; reads a few us high behind a long-tailed predecessor -- rocprofv3, profiles/, is the reference)
             "step_kernels": step_kernels,
@@ -796,6 +838,9 @@ def main():
             "kernels_us_dispatch_start_to_stop": kernels_us,
             "courant_violations": violations,
         }
+        if "k_tm" in run_kernels:
+            traffic_tm, note_tm = load_pmc_traffic(nx, ny, a.dtype, os.path.join(ROOT, "profiles", "tm_pmc.json"))
+            out["roofline"] = roofline_of_the_kept_form(run_kernels, out["roofline"], traffic_tm, note_tm, nprof, esz, cells)
         if not dist_path and not a.no_extras:
             try:
                 out["sustained"] = sustained_record(api, nx, ny, a.dtype, a.ic, local, a.jacobi_iters, dt, a.sustained_steps)

@@ -121,10 +121,10 @@ inline bool buffer_stores_ok(const vof2d_ctx* h) {
 // ------------------------------------------------------------------ launches
 constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe
 enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
-                kRhs, kOther, kTransport, NKERNELS };
+                kRhs, kOther, kTransport, kJacobiPair, kTM, NKERNELS };
 const char* const kKernelNames[NKERNELS] = {"k_momentum", "k_set_bc", "k_jacobi", "k_jacobi_tb", "k_correct",
                                             "k_fct_x", "k_fct_y", "k_normals", "k_kappa", "k_predictor", "k_rhs",
-                                            "other", "k_transport"};
+                                            "other", "k_transport", "k_jacobi_pair", "k_tm"};
 
 // One place through which every kernel is launched.  In profiling mode the dispatch carries its
 // own start/stop events (hipExtLaunchKernelGGL: the begin/end timestamps of the dispatch itself,
@@ -263,10 +263,10 @@ struct L {
     const unsigned pairs = tp.masks ? (unsigned)tp.waves : (unsigned)(((last - first + R) / R) * ntt);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 2);
     if (bs)
-      launch_block(h, kJacobiTB, k_jacobi_pair<T, V, 5, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
+      launch_block(h, kJacobiPair, k_jacobi_pair<T, V, 5, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
                    (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last);
     else
-      launch_block(h, kJacobiTB, k_jacobi_pair<T, V, 5, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
+      launch_block(h, kJacobiPair, k_jacobi_pair<T, V, 5, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
                    (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last);
   }
   // the work plan of the step's five-sweep launches (see tb_make_plan): active on parity-keyed step
@@ -402,11 +402,11 @@ struct L {
     const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf) + (tp.masks ? 1u : 0u);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 4);
     if (bs)
-      launch_block(h, kTransport, k_tm<T, V, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+      launch_block(h, kTM, k_tm<T, V, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
              F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last);
     else
-      launch_block(h, kTransport, k_tm<T, V, YFIRST, STORE_UV, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+      launch_block(h, kTM, k_tm<T, V, YFIRST, STORE_UV, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
              F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last);
   }

@@ -765,7 +765,18 @@ int vof_profile_steps(vof2d_handle h, int64_t nsteps) {
   while (done < nsteps) {
     h->timed = 0;
     int batch = 0;
-    while (done + batch < nsteps && h->timed + per_step <= vof2d_ctx::kMaxTimed) {
+    // A handle whose batch graphs run the k_tm form is profiled in that form: the same launch sequence, eagerly, every
+    // launch between its own event pair (k_momentum, K x k_jacobi_pair / 2 K x k_jacobi_tb, K - 1 x k_tm, k_transport).
+    const bool tm_form = ((h->fuse_tm > 0 && tm_eligible(h)) || (tm_auto(h) && h->tm_decided && h->tm_choice == 1)) &&
+                         !h->f_ghosts_dirty && !h->uv_ghosts_dirty && step_leaves_ghosts_virtual(h) && nsteps - done >= 2;
+    if (tm_form) {
+      const int K = nsteps - done >= 8 ? 8 : 2;
+      DISPATCH_T(h, enqueue_steps_tm<double>(h, h->istep + 1, K), enqueue_steps_tm<float>(h, h->istep + 1, K));
+      h->istep += K;
+      h->ghosts_virtual = true;
+      batch = K;
+    }
+    while (!tm_form && done + batch < nsteps && h->timed + per_step <= vof2d_ctx::kMaxTimed) {
       h->istep += 1;
       const bool lean = !h->f_ghosts_dirty;
       const bool virt = step_leaves_ghosts_virtual(h);

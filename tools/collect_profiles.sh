@@ -30,7 +30,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${T}
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${T}_tmwrite -- python3 tools/bound_run.py --steps 60 > gpurun_out/${T}_tmwrite.log 2>&1
 unset VOF2D_OVERLAP_HALVES VOF2D_FUSE_TM
 python3 tools/summarize_overlap_trace.py $T one-chain=gpurun_out/${T}_long chains=gpurun_out/${T}_long2 k_tm=gpurun_out/${T}_long3 --cmd "rocprofv3 --kernel-trace -- python3 tools/bound_run.py --steps 1000 (VOF2D_OVERLAP_HALVES=0 VOF2D_FUSE_TM=0 for the one-chain run, VOF2D_FUSE_TM=0 for chains, VOF2D_OVERLAP_HALVES=0 VOF2D_FUSE_TM=1 for k_tm)"
-python3 tools/summarize_profiles.py ${T}_tm "$(find gpurun_out/${T}_long3 -name '*kernel_stats.csv' | head -1)" "$(find gpurun_out/${T}_tmfetch -name '*counter_collection.csv' | head -1)" "$(find gpurun_out/${T}_tmwrite -name '*counter_collection.csv' | head -1)" --no-json --cmd "VOF2D_OVERLAP_HALVES=0 VOF2D_FUSE_TM=1 rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/bound_run.py --steps 1000"
+python3 tools/summarize_profiles.py ${T}_tm "$(find gpurun_out/${T}_long3 -name '*kernel_stats.csv' | head -1)" "$(find gpurun_out/${T}_tmfetch -name '*counter_collection.csv' | head -1)" "$(find gpurun_out/${T}_tmwrite -name '*counter_collection.csv' | head -1)" --tm-json --cmd "VOF2D_OVERLAP_HALVES=0 VOF2D_FUSE_TM=1 rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/bound_run.py --steps 1000"
 # summaries, here: profiles/<tag>_*.md and profiles/jacobi_pmc.json (with the hash of the sources just profiled)
 f() { find gpurun_out/${T}_$1 -name "*$2" | head -1; }
 python3 tools/summarize_profiles.py $T "$(f stats kernel_stats.csv)" "$(f fetch counter_collection.csv)" "$(f write counter_collection.csv)" --cmd "VOF2D_OVERLAP_HALVES=0 rocprofv3 --kernel-trace --stats --output-format csv -- $B"
@@ -43,7 +43,7 @@ python3 bench.py --nx 2048 -ic 2 --dtype f32 --no-cpu-baseline > gpurun_out/${T}
 python3 bench.py --nx 4096 --dtype f32 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_4096_f32.json 2>> gpurun_out/${T}_bench.err
 for n in 128 1024 2048 8192; do python3 bench.py --nx $n --no-cpu-baseline --no-extras --profile-steps 40 $([ $n = 8192 ] && echo "--steps 60 --warmup 10") 2>> gpurun_out/${T}_bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%s: %.4f ms/step, %.2f G cell-updates/s' % (d['config']['workload'], d['ms_per_step'], d['value']/1e9))"; done > gpurun_out/${T}_sizes.txt 2>&1
 mkdir -p gpurun_out/${T}_profiles
-cp profiles/${T}_overlap_trace.md profiles/${T}_tm_kernel_stats.md profiles/${T}_tm_hbm_pmc.md profiles/${T}_kernel_stats.md profiles/${T}_hbm_pmc.md profiles/${T}_long_kernel_stats.md profiles/${T}_f32_kernel_stats.md profiles/${T}_sq_counters.md profiles/jacobi_pmc.json gpurun_out/${T}_profiles/ 2>/dev/null
+cp profiles/${T}_overlap_trace.md profiles/${T}_tm_kernel_stats.md profiles/${T}_tm_hbm_pmc.md profiles/${T}_kernel_stats.md profiles/${T}_hbm_pmc.md profiles/${T}_long_kernel_stats.md profiles/${T}_f32_kernel_stats.md profiles/${T}_sq_counters.md profiles/jacobi_pmc.json profiles/tm_pmc.json gpurun_out/${T}_profiles/ 2>/dev/null
 cp gpurun_out/${T}_bench.json gpurun_out/${T}_bench_2048_bubble_f32.json gpurun_out/${T}_bench_4096_f32.json gpurun_out/${T}_sizes.txt gpurun_out/${T}_profiles/
 find gpurun_out/${T}_stats gpurun_out/${T}_fetch gpurun_out/${T}_write gpurun_out/${T}_long gpurun_out/${T}_long2 gpurun_out/${T}_long3 gpurun_out/${T}_tmfetch gpurun_out/${T}_tmwrite gpurun_out/${T}_f32 gpurun_out/${T}_sq_f32 gpurun_out/${T}_sq_f64 -type f -size +6M -delete      # (gpurun brings back 64 MiB at most; the raw per-kernel CSVs stay)
 ls gpurun_out/${T}_profiles; cut -c1-400 gpurun_out/${T}_bench.json; cat gpurun_out/${T}_sizes.txt

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--cmd", default="")
     ap.add_argument("--no-json", action="store_true", help="do not rewrite profiles/jacobi_pmc.json (a pass over another schedule)")
+    ap.add_argument("--tm-json", action="store_true", help="the passes are of the k_tm form: write profiles/tm_pmc.json (k_tm, k_jacobi_pair) instead")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -69,6 +70,18 @@ def main():
                     hbm = (2 * v["fetch_kib"] + v["write_kib"]) * 1024
                     f.write("| %s | %.0f | %.0f | %.1f | %.2f |\n" % (k, v["fetch_kib"], v["write_kib"], hbm / 1e6,
                                                                      hbm / (a.nx * a.ny * esz)))
+        if a.tm_json:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "taichi-2d-vof_amd"))
+            from vof2d._lib import kernel_source_hash
+            rec = {"nx": a.nx, "ny": a.ny, "dtype": a.dtype, "tag": a.tag, "hbm_bytes_per_launch": {}, "kernel_source_sha256": kernel_source_hash(),
+                   "rule": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes", "kernels": {}}
+            for key, pat in (("tm", "k_tm<"), ("pair", "k_jacobi_pair<")):
+                vs = [(2 * v["fetch_kib"] + v["write_kib"]) * 1024 for k, v in agg.items() if pat in k and "fetch_kib" in v and "write_kib" in v]
+                if vs:
+                    rec["hbm_bytes_per_launch"][key] = sum(vs) / len(vs)
+                    rec["kernels"][key] = [k for k in agg if pat in k]
+            json.dump(rec, open(os.path.join(out, "tm_pmc.json"), "w"), indent=1)
+            return
         if a.no_json:
             return
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "taichi-2d-vof_amd"))
