@@ -742,9 +742,12 @@ def main():
                 prof = e1.profile_steps(nprof)
                 # ... and the launches of the form the handle keeps (k_tm / k_jacobi_pair on a large fp64 grid), the same
                 # steps of the same run: the handle is warmed (which decides the form) and put back to the initial state
-                warm_handle(e1, a.ic, nx, ny, a.dtype)
-                e1.step(10)
-                prof_run = e1.profile_steps(nprof) if e1.get_counter("tm_choice") == 1 else {}
+                kept_tm = eng.get_counter("tm_choice") == 1 or (eng.get_counter("tm_choice") < 0 and eng.get_counter("tm_steps") > 0)
+                if kept_tm:
+                    e1.set_param("fuse_tm", 1)     # (the form the timed handle kept, whatever this one would have measured)
+                    warm_handle(e1, a.ic, nx, ny, a.dtype)
+                    e1.step(10)
+                    prof_run = e1.profile_steps(nprof)
             finally:
                 e1.close()
         except Exception as exc:      # e.g. not enough free HBM for a second engine: the line survives without the breakdown

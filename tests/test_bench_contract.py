@@ -197,3 +197,25 @@ def test_traffic_is_quoted_only_for_the_kernel_sources_it_was_measured_on(tmp_pa
     p.write_text(json.dumps(rec))
     assert bench.load_pmc_traffic(4096, 4096, "f64", str(p))[0] == {}
     assert bench.load_pmc_traffic(4096, 4096, "f64", str(tmp_path / "none.json")) == ({}, "no committed PMC profile")
+
+
+@pytest.mark.gpu
+def test_bench_reports_the_form_the_handle_keeps():
+    """A large fp64 grid: the handle times its two batch forms and keeps one (config.step_schedule); if that is the k_tm
+    form, `roofline` names k_tm (8 algorithmic passes), carries the Jacobi kernel of the step and the record of the four
+    classic kernels one at a time; else it is that record itself."""
+    d, _ = _run_bench(["--nx", "3072", "--steps", "16", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--no-scaling-reference",
+                    "--profile-steps", "24"])
+    cfg, rf = d["config"], d["roofline"]
+    assert cfg["handle_warm_steps"] == 41 and cfg["handle_warm_ms"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["bound"] == "hbm"
+    if cfg["step_schedule"].startswith("k_tm"):
+        assert rf["kernel"] == "k_tm" and rf["algorithmic_passes"] == 8 and rf["algorithmic_bytes_per_launch"] == 8 * 8 * 3072 * 3072
+        assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 1e-3 * rf["achieved"]   # (us rounded to 0.01)
+        run = d["step_kernels_as_run"]
+        assert set(run) >= {"k_tm", "k_jacobi_pair"} and abs(run["k_jacobi_pair"]["launches_per_step"] - 1.0) < 1e-9
+        assert 0.8 <= run["k_tm"]["launches_per_step"] < 1.0 and rf["jacobi_kernel_of_the_step"]["sweeps_per_launch"] == 10
+        assert rf["one_kernel_at_a_time"]["kernel"] == "k_jacobi_tb" and 0 < rf["one_kernel_at_a_time"]["frac"] < 1
+    else:
+        assert rf["kernel"] == "k_jacobi_tb" and not d["step_kernels_as_run"]
+    assert rf["north_star_single_sweep"]["kernel"] == "k_jacobi"
