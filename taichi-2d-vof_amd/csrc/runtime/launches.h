@@ -396,7 +396,7 @@ struct L {
     int R = h->tm_rows;
     if (R <= 0) {
       R = (int)(((long)(h->g.ihi - h->g.ilo + 1) * ntf / 2765 + 4) / 8 * 8);
-      R = R < 16 ? 16 : (R > 64 ? 64 : R);
+      R = R < 16 ? 16 : (R > 104 ? 104 : R);   // (8192^2: 104 rows 1.637 ms/step, 64 rows 1.656)
     }
     const TbPlan tp = tb_plan(h, adapt_par);
     const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf) + (tp.masks ? 1u : 0u);
