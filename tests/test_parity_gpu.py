@@ -1,6 +1,8 @@
 """GPU parity: the HIP library (through the C ABI) against the CPU oracle on the same inputs.
 Bar: value-for-value equality (IEEE ==) in fp64 and fp32 -- both sides evaluate the reference's
 expressions in the same order with FMA contraction off, so no tolerance is needed."""
+import os
+
 import numpy as np
 import pytest
 
@@ -889,3 +891,23 @@ def test_jacobi_pair_changes_no_value(hip_api, oracle_api, dtype, ic, n, ring, r
     assert a.get_counter("tm_steps") == 36 and a.get_counter("pair_launches") == 36
     if ring:
         assert planned >= 2, planned
+
+
+@pytest.mark.gpu
+def test_pair_kernels_reproduce_the_128_fixture(hip_api):
+    """BASELINE configs[0] (128^2 dam-break fp64, 1000 steps) with k_tm and k_jacobi_pair forced: the committed fixture
+    (tests/golden/dam128_f64.npz -- the reference's own run reproduces it, test_ref_golden.py) bit for bit at steps
+    100 and 1000, 998 of the steps replayed from k_tm batch graphs."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dam128_f64.npz"))
+    e = engine(hip_api, 128, 128, "f64", "f32", ic=1)
+    e.set_param("overlap_halves", 0)
+    e.set_param("fuse_tm", 1)
+    e.set_param("jacobi_pair", 2)
+    for st in (100, 1000):
+        e.step(st - e.istep)
+        for f in STATE:
+            key = "%s_%d" % (f, st)
+            if key in z:
+                x = e.get(f)
+                assert np.array_equal(x, z[key]), "step %d: %s" % (st, diff_report(x, z[key], f))
+    assert e.get_counter("tm_steps") == 998 and e.get_counter("pair_launches") == 998
