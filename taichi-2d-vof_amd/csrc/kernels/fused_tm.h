@@ -10,9 +10,11 @@
 // the caller wants them in memory (STORE_UV: the last step of a batch; nothing inside a batch reads them).
 //   reads  F, u*, v*, p (4 passes)      writes F'', u*', v*', rhs' (4 passes) [+ u, v]        instead of 7 + 6
 // Same per-cell functions, same operands, same order as the two kernels: the values are theirs.
-//   * tile: 128 columns, the transport march is valid on [c0 + 8, c0 + 119] (TileHalo::transport), the momentum
-//     march on what it can form from those: [c0 + 11, c0 + 116]; tiles advance by 104 columns (HF = 12 keeps a
-//     lane's first column odd, i.e. its 16-byte loads aligned), everything is stored on [c0 + 12, c0 + 115];
+//   * tile: 128 columns; the transport march is valid on [c0 + 4, c0 + 123] (the y sweep resolves its +-3 dependency
+//     across lanes), the momentum march on what it can form from those (it reaches 3 columns to either side):
+//     [c0 + 7, c0 + 120]; HF = 8 keeps a lane's first column odd, i.e. its 16-byte loads aligned: tiles advance by
+//     112 columns (7 cache lines: every stored segment starts and ends on a line), everything is stored on
+//     [c0 + 8, c0 + 119];
 //   * rows: a chunk [ma, mb] of momentum output needs F'' rows ma-3 .. mb+3 and u, v rows ma-2 .. mb+2, so the
 //     transport wave marches t = ma-5 .. mb+6 (producing u[t], v[t], F''[t-3]) and the momentum wave runs its
 //     iteration r' = t - 5 at step t: it reads F''[r'] (and F''[1] for the mirrored ghost row 0), produced at
@@ -29,7 +31,7 @@
 
 namespace vof {
 
-struct TmGeom { static constexpr int HF = 12; };   // invalid columns per tile side of the fused march
+struct TmGeom { static constexpr int HF = 8; };   // invalid columns per tile side of the fused march: 4 (transport) + 3 (momentum), rounded up to even
 
 template <typename T, int V>
 struct TmRing {
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
                                             T* __restrict__ vs_out, T* __restrict__ rhs,
                                             unsigned long long* __restrict__ courant, int R, TbPlan tp, int first, int last) {
   constexpr int W = 64 * V, HF = TmGeom::HF, STRIDE = W - 2 * HF;
-  static_assert(HF >= TileHalo::transport + 3 && HF % V == 0, "momentum's inputs must lie inside the transport march's valid columns");
+  static_assert(HF >= 4 + 3 && HF % V == 0, "momentum's inputs must lie inside the transport march's valid columns");
   static_assert(sizeof(TbPlanShared) <= sizeof(TmRing<double, 2>) / 2, "the planner block borrows the ring's LDS");
   __shared__ __attribute__((aligned(16))) char smem[sizeof(TmRing<T, V>) > sizeof(TbPlanShared) ? sizeof(TmRing<T, V>) : sizeof(TbPlanShared)];
   const int plan_blocks = tp.masks != nullptr ? 1 : 0;

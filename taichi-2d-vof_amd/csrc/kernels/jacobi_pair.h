@@ -9,8 +9,8 @@
 // 3 array passes per 2 * TS sweeps instead of 6.  The register pipeline of each wave is k_jacobi_tb's (a single wave
 // doing 2 * TS stages needs 250 VGPRs, or an rhs ring in LDS and twice the serial work per row: both measured slower).
 // Same stage arithmetic, same operands, same order: the values are those of two k_jacobi_tb launches.
-//   * tile: 128 columns; the first march loses TS + 1 columns per side (rounded to V), the second as many again:
-//     H = 12, tiles advance by 104 columns;
+//   * tile: 128 columns; each march loses TS columns per side (TS - 1 cross-lane sweeps + the first sweep's DPP
+//     neighbours): H = 10, tiles advance by 108 columns;
 //   * rows: the pair produces rows [ra, rb]; the first march produces [ra - TS, rb + TS] from p rows [ra - 2 TS, rb + 2 TS];
 //   * lockstep, one barrier per step: at step tau the first wave runs its sub-iteration t = tau (writing its result
 //     row t - TS and the rhs row t - 1 into the rings), the second its sub-iteration t = tau - (TS + 2), which reads
@@ -47,7 +47,7 @@ __device__ __forceinline__ void jacobi_pair_march(const Geom& g, const Consts<T>
                                                   const T* __restrict__ rhs, T* __restrict__ pn, JpRing<T, V>& lds,
                                                   int c0, int lane, int ra, int rb, int& hit) {
   constexpr int W = 64 * V;
-  constexpr int H = 2 * (((TS - 1 + 1 + V - 1) / V) * V);
+  constexpr int H = ((2 * TS + V - 1) / V) * V;   // TS invalid columns per side and march (TS - 1 cross-lane sweeps + the first sweep's DPP neighbours)
   const int j0 = c0 + lane * V;
   const int nx = g.nx, ny = g.ny;
   const int jlo = c0 + H > 1 ? c0 + H : 1;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(128) void k_jacobi_pair(Geom g, Consts<T> c, const 
                                                      const T* __restrict__ rhs, T* __restrict__ pn, int R, int ntt,
                                                      TbPlan tp, int first, int last) {
   constexpr int W = 64 * V;
-  constexpr int H = 2 * (((TS - 1 + 1 + V - 1) / V) * V);
+  constexpr int H = ((2 * TS + V - 1) / V) * V;   // TS invalid columns per side and march (TS - 1 cross-lane sweeps + the first sweep's DPP neighbours)
   constexpr int STRIDE = W - 2 * H;
   __shared__ __attribute__((aligned(16))) JpRing<T, V> lds;
   if (last < first) { first = g.ilo; last = g.ihi; }

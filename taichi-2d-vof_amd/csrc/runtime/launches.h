@@ -248,7 +248,7 @@ struct L {
            h->d.jacobi_iters % 10 == 0;
   }
   static int jacobi_pair_geom(vof2d_ctx* h, int& ntt) {
-    constexpr int ST = 64 * V - 2 * 2 * (((5 - 1 + 1 + V - 1) / V) * V);   // must match the kernel: 104 columns
+    constexpr int ST = 64 * V - 2 * (((2 * 5 + V - 1) / V) * V);   // must match the kernel: 108 columns
     ntt = (h->g.ny + ST - 1) / ST;
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 2);
     const long cap = bs ? resident_blocks(h, k_jacobi_pair<T, V, 5, true>, 128) : resident_blocks(h, k_jacobi_pair<T, V, 5, false>, 128);
