@@ -391,12 +391,13 @@ struct L {
     if (last < first) { first = h->g.ilo; last = h->g.ihi; }
     constexpr int ST = 64 * V - 2 * TmGeom::HF;
     const int ntf = (h->g.ny + ST - 1) / ST;
-    // pair chunks: about two residency rounds (6 pairs per CU: 24 KB of LDS each) -- one round of long chunks is slow
-    // (3072^2: 64 rows 0.432 ms/step, 32 rows 0.346; 4096^2: 96 rows 0.627, 64 rows 0.538, 32 rows 0.554)
+    // pair chunks: about two and a half residency rounds (6 pairs per CU: 24 KB of LDS each) -- 4096^2, 112-column tiles:
+    // 24 rows 0.5115 ms/step, 32 0.4938, 40 0.4847, 44 0.4868, 48 0.4892, 56 0.4912, 64 0.4873, 72 0.5213 (1.4 rounds);
+    // 3072^2: 24 0.332, 32 0.329, 40 0.338; 8192^2: 80 1.575, 104 1.582, 128 1.617, 160 1.607
     int R = h->tm_rows;
     if (R <= 0) {
-      R = (int)(((long)(h->g.ihi - h->g.ilo + 1) * ntf / 2765 + 4) / 8 * 8);
-      R = R < 16 ? 16 : (R > 104 ? 104 : R);   // (8192^2: 104 rows 1.637 ms/step, 64 rows 1.656)
+      R = (int)(((long)(h->g.ihi - h->g.ilo + 1) * ntf / 3800 + 4) / 8 * 8);
+      R = R < 16 ? 16 : (R > 96 ? 96 : R);
     }
     const TbPlan tp = tb_plan(h, adapt_par);
     const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf) + (tp.masks ? 1u : 0u);
