@@ -37,13 +37,17 @@ python3 tools/summarize_profiles.py $T "$(f stats kernel_stats.csv)" "$(f fetch 
 python3 tools/summarize_profiles.py ${T}_long "$(f long kernel_stats.csv)" --cmd "VOF2D_OVERLAP_HALVES=0 rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/bound_run.py --steps 1000"
 python3 tools/summarize_profiles.py ${T}_f32 "$(f f32 kernel_stats.csv)" --nx 2048 --ny 2048 --dtype f32 --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- $F32"
 python3 tools/summarize_sq.py $T f32="$(f sq_f32 counter_collection.csv)" f64="$(f sq_f64 counter_collection.csv)" --nx 2048 --ny 2048 --cmd "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -- python3 bench.py --nx 2048 -ic 2 --dtype f32|f64 --steps 20 --warmup 3 --no-cpu-baseline --no-extras --jacobi-sweeps-timed 20" > /dev/null
+# the bench command as the driver runs it (default environment: the form the handle keeps), under the profiler
+rm -rf gpurun_out/${T}_default
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_default -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-scaling-reference --no-extras > gpurun_out/${T}_default.log 2>&1
+python3 tools/summarize_profiles.py ${T}_default "$(find gpurun_out/${T}_default -name '*kernel_stats.csv' | head -1)" --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-scaling-reference --no-extras"
 # the bench lines LAST: roofline.traffic is quoted from the jacobi_pmc.json written a moment ago
 python3 bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 python3 bench.py --nx 2048 -ic 2 --dtype f32 --no-cpu-baseline > gpurun_out/${T}_bench_2048_bubble_f32.json 2>> gpurun_out/${T}_bench.err
 python3 bench.py --nx 4096 --dtype f32 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_4096_f32.json 2>> gpurun_out/${T}_bench.err
 for n in 128 1024 2048 8192; do python3 bench.py --nx $n --no-cpu-baseline --no-extras --profile-steps 40 $([ $n = 8192 ] && echo "--steps 60 --warmup 10") 2>> gpurun_out/${T}_bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%s: %.4f ms/step, %.2f G cell-updates/s' % (d['config']['workload'], d['ms_per_step'], d['value']/1e9))"; done > gpurun_out/${T}_sizes.txt 2>&1
 mkdir -p gpurun_out/${T}_profiles
-cp profiles/${T}_overlap_trace.md profiles/${T}_tm_kernel_stats.md profiles/${T}_tm_hbm_pmc.md profiles/${T}_kernel_stats.md profiles/${T}_hbm_pmc.md profiles/${T}_long_kernel_stats.md profiles/${T}_f32_kernel_stats.md profiles/${T}_sq_counters.md profiles/jacobi_pmc.json profiles/tm_pmc.json gpurun_out/${T}_profiles/ 2>/dev/null
+cp profiles/${T}_default_kernel_stats.md profiles/${T}_overlap_trace.md profiles/${T}_tm_kernel_stats.md profiles/${T}_tm_hbm_pmc.md profiles/${T}_kernel_stats.md profiles/${T}_hbm_pmc.md profiles/${T}_long_kernel_stats.md profiles/${T}_f32_kernel_stats.md profiles/${T}_sq_counters.md profiles/jacobi_pmc.json profiles/tm_pmc.json gpurun_out/${T}_profiles/ 2>/dev/null
 cp gpurun_out/${T}_bench.json gpurun_out/${T}_bench_2048_bubble_f32.json gpurun_out/${T}_bench_4096_f32.json gpurun_out/${T}_sizes.txt gpurun_out/${T}_profiles/
-find gpurun_out/${T}_stats gpurun_out/${T}_fetch gpurun_out/${T}_write gpurun_out/${T}_long gpurun_out/${T}_long2 gpurun_out/${T}_long3 gpurun_out/${T}_tmfetch gpurun_out/${T}_tmwrite gpurun_out/${T}_f32 gpurun_out/${T}_sq_f32 gpurun_out/${T}_sq_f64 -type f -size +6M -delete      # (gpurun brings back 64 MiB at most; the raw per-kernel CSVs stay)
+find gpurun_out/${T}_stats gpurun_out/${T}_fetch gpurun_out/${T}_write gpurun_out/${T}_long gpurun_out/${T}_long2 gpurun_out/${T}_default gpurun_out/${T}_long3 gpurun_out/${T}_tmfetch gpurun_out/${T}_tmwrite gpurun_out/${T}_f32 gpurun_out/${T}_sq_f32 gpurun_out/${T}_sq_f64 -type f -size +6M -delete      # (gpurun brings back 64 MiB at most; the raw per-kernel CSVs stay)
 ls gpurun_out/${T}_profiles; cut -c1-400 gpurun_out/${T}_bench.json; cat gpurun_out/${T}_sizes.txt
