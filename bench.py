@@ -301,16 +301,17 @@ def supervise(a, rank):
 
 # --------------------------------------------------------------------------------------------------
 # single-GPU extras
-HANDLE_WARM_STEPS = 41   # 1 eager step + 5 batches of 8: the step graphs of both forms captured, four of the batches timed by the handle
+HANDLE_WARM_STEPS = 19   # 1 eager step + a batch of 16 + a batch of 2: the step graphs of the handle's batch form captured and replayed once
 
 
 def warm_handle(e, ic, nx, ny, dtype):
-    """A handle captures its step graphs on its first steady-state steps and, on a large fp64 grid, times its two batch
-    forms against each other on the next 32 (chains of the four kernels against k_tm) -- once, 40-80 ms
-    all told.  A bench of a few dozen steps is not the place to charge that to, so the handle is warmed and then put
-    back to the initial state: all-zero F, u, v, p as a new handle holds them, set_init_F (which, like 2dvof.py:141-147,
-    only writes the liquid cells of the dam), istep = 0.  tests/test_parity_gpu.py checks that a handle treated like
-    this repeats a new handle's run value for value.  Returns the wall time of the warm steps in ms."""
+    """A handle captures its step graphs on its first steady-state steps (and, on a large fp64 grid, looks at F once to
+    choose its batch form: a rule on the state, vof_step) -- once, 20-40 ms all told.  A bench of a few dozen steps is
+    not the place to charge that to, so the handle is warmed and then put back to the initial state: all-zero F, u, v,
+    p as a new handle holds them, set_init_F (which, like 2dvof.py:141-147, only writes the liquid cells of the dam),
+    istep = 0.  tests/test_parity_gpu.py checks that a handle treated like this repeats a new handle's run value for
+    value.  Returns (wall time of the warm steps in ms, Courant violations counted during them -- the device counter is
+    not reset with the state)."""
     import numpy as np
     e.sync()
     t0 = time.perf_counter()
@@ -324,7 +325,7 @@ def warm_handle(e, ic, nx, ny, dtype):
     e.set_init_F(ic)
     e.istep = 0
     e.sync()
-    return ms
+    return ms, e.get_counter("courant_violations")
 
 
 def _batch_form(form):
@@ -350,7 +351,7 @@ def sustained_record(api, nx, ny, dtype, ic, local, jacobi_iters, dt, nsteps, bl
     from vof2d.engine import Engine, make_desc
     e = Engine(api, make_desc(api, nx, ny, dtype, "f32", device=local, jacobi_iters=jacobi_iters, dt=dt))
     e.set_init_F(ic)
-    warm_ms = warm_handle(e, ic, nx, ny, dtype)
+    warm_ms, warm_viol = warm_handle(e, ic, nx, ny, dtype)
     blocks = []
     t_all = time.perf_counter()
     for _ in range(max(1, nsteps // block)):
@@ -360,7 +361,7 @@ def sustained_record(api, nx, ny, dtype, ic, local, jacobi_iters, dt, nsteps, bl
         blocks.append(1e3 * (time.perf_counter() - t0) / block)
     total = time.perf_counter() - t_all
     n = block * len(blocks)
-    viol = e.get_counter("courant_violations")
+    viol = e.get_counter("courant_violations") - warm_viol
     e_form = (e.get_param("overlap_halves"), e.get_counter("tm_choice"), e.get_counter("tm_steps"))
     e.close()
     return {"steps": n, "block": block, "ms_per_step_blocks": [round(b, 4) for b in blocks],
@@ -368,7 +369,7 @@ def sustained_record(api, nx, ny, dtype, ic, local, jacobi_iters, dt, nsteps, bl
             "value": nx * ny * n / total, "unit": "cell-updates/s", "courant_violations": viol,
             "handle_warm_steps_ms": round(warm_ms, 2), "batch_form": _batch_form(e_form),
             "note": "steps 1..%d from the initial state on a warm handle (%d steps, then F = u = v = p = 0, set_init_F, "
-                    "istep = 0: its step graphs are captured and its batch form chosen), wall clock incl. one sync per block" % (n, HANDLE_WARM_STEPS)}
+                    "istep = 0: its step graphs are captured), wall clock incl. one sync per block" % (n, HANDLE_WARM_STEPS)}
 
 
 def residual_solve_1024(api, local, dtype="f64", tol=1e-6, cap=3000000, every=5000):
@@ -484,7 +485,8 @@ def roofline_of_the_kept_form(run_kernels, classic, traffic_tm, note_tm, nprof, 
     dominant kernel -- about two thirds of the step.  Algorithmic bytes by SURVEY 8d's rule (every distinct array a
     kernel reads or writes, once): 8 passes for k_tm, 3 for k_jacobi_pair's ten sweeps.  The rule counts what a
     kernel has to move, so a kernel that fuses more has fewer bytes to show for its time: next to `frac` stand the
-    bytes of the kernels it replaces, and the whole step on the reference's 19 passes is `step_frac_of_peak_algorithmic`.
+    bytes of the kernels it replaces; the whole step on its own kernel list is `step_frac_of_peak_algorithmic`
+    (config.step_frac_of_peak: own list, the four-kernel schedule's 19 passes, counter traffic, side by side).
     `one_kernel_at_a_time` is the record of the four classic kernels (k_jacobi_tb: the previous rounds' `roofline`)."""
     tm = run_kernels["k_tm"]
     us = tm["us_per_launch_dispatch"]
@@ -557,8 +559,10 @@ def main():
         api = hip_api()
         eng = Engine(api, make_desc(api, nx, ny, a.dtype, "f32", device=local, jacobi_iters=a.jacobi_iters, dt=dt))
         eng.set_init_F(a.ic)
-        handle_warm_ms = warm_handle(eng, a.ic, nx, ny, a.dtype)
+        handle_warm_ms, warm_violations = warm_handle(eng, a.ic, nx, ny, a.dtype)
         elapsed = timed_steps(eng, a.warmup, a.steps)
+        # (read now: the knob changes of the Jacobi timing below make the handle forget its choice)
+        form_state = (eng.get_param("overlap_halves"), eng.get_counter("tm_choice"), eng.get_counter("tm_steps"), eng.get_param("gas_share"))
         solver = None
     native_ok = False
     if dist_path and a.exchange == "native":
@@ -691,7 +695,7 @@ def main():
     eng.set_param("jacobi_tb", 1)
     ms_sweep_1 = eng.time_jacobi(max(2, a.jacobi_sweeps_timed // 2 * 2))
     eng.set_param("jacobi_tb", tb)
-    violations = eng.get_counter("courant_violations")
+    violations = eng.get_counter("courant_violations") - (warm_violations if not dist_path else 0)
     achieved_1 = sweep_bytes / (ms_sweep_1 * 1e-3) / 1e9
     traffic, traffic_note = load_pmc_traffic(nx, ny, a.dtype) if not dist_path else ({}, "N > 1")
     fused = {"kernel": "k_jacobi_tb", "sweeps_per_launch": tb, "bound": "hbm (actual traffic: lead-in rows + tile overlap)",
@@ -742,9 +746,9 @@ def main():
                 prof = e1.profile_steps(nprof)
                 # ... and the launches of the form the handle keeps (k_tm / k_jacobi_pair on a large fp64 grid), the same
                 # steps of the same run: the handle is warmed (which decides the form) and put back to the initial state
-                kept_tm = eng.get_counter("tm_choice") == 1 or (eng.get_counter("tm_choice") < 0 and eng.get_counter("tm_steps") > 0)
+                kept_tm = form_state[1] == 1 or (form_state[1] < 0 and form_state[2] > 0)
                 if kept_tm:
-                    e1.set_param("fuse_tm", 1)     # (the form the timed handle kept, whatever this one would have measured)
+                    e1.set_param("fuse_tm", 1)     # (the form the timed handle runs)
                     warm_handle(e1, a.ic, nx, ny, a.dtype)
                     e1.step(10)
                     prof_run = e1.profile_steps(nprof)
@@ -779,6 +783,28 @@ def main():
     except Exception:
         one_kernel_transport = False
     ARRAYS_PER_STEP = ARRAYS_PER_STEP_FULL if one_kernel_transport else ARRAYS_PER_STEP_STRIP
+    # What the step AS THE HANDLE RAN IT has to move, by SURVEY 8d's rule applied to its own kernel list (every distinct
+    # array a kernel reads or writes, once, times its launches per step, from the in-situ profile of the kept form):
+    # 8 x 0.875 (k_tm) + 3 (k_jacobi_pair: ten sweeps) + 13 x 0.125 (the plain k_momentum / k_transport at the ends of a
+    # 16-step batch) = 11.6 passes where the pair kernels run, 6 + 2 x 3 + 7 = 19 for the four-kernel schedule.  Three
+    # step fractions stand side by side in `config`: on this list, on the 19 passes of the four-kernel schedule every
+    # earlier round quoted, and on the HBM traffic the counters saw.
+    own_kernels = run_kernels if "k_tm" in run_kernels else step_kernels
+    own_passes = sum(v["launches_per_step"] * v["algorithmic_passes"] for v in own_kernels.values()) if own_kernels else float(ARRAYS_PER_STEP)
+    step_s = elapsed / a.steps
+    traffic_all, traffic_all_note = ({}, "N > 1")
+    if not dist_path:
+        traffic_all, traffic_all_note = load_pmc_traffic(nx, ny, a.dtype, os.path.join(ROOT, "profiles", "tm_pmc.json" if "k_tm" in run_kernels else "jacobi_pmc.json"))
+    fam = {"k_tm": "tm", "k_jacobi_pair": "pair", "k_jacobi_tb": "tb", "k_momentum": "momentum", "k_transport": "transport", "k_jacobi": "single"}
+    step_traffic = None
+    if own_kernels and all(fam.get(k) in traffic_all for k in own_kernels):
+        step_traffic = sum(v["launches_per_step"] * traffic_all[fam[k]] for k, v in own_kernels.items())
+    fractions = {
+        "own_kernel_list": own_passes * esz * cells / step_s / 1e9 / HBM_PEAK_GBS,
+        "reference_schedule_19_passes": ARRAYS_PER_STEP * esz * cells / step_s / 1e9 / HBM_PEAK_GBS,
+        "counter_traffic": (step_traffic / step_s / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
+        "counter_traffic_note": traffic_all_note if step_traffic else ("no committed PMC passes for every kernel of the step (%s)" % traffic_all_note),
+    }
     if rank == 0 and dist_path:
         # which carrier moved the halos, BEFORE the line (a reader of the log sees it even if the line is lost)
         print("[bench] carrier: %s exchange, overlap mode %s%s, %s" % (
@@ -809,12 +835,17 @@ def main():
                 "exchange_graph": (eng.comm_info()[1] == 1) if exchange == "native" else None,
                 "exchange_graph_steps_in_timed_region": graph_steps,
                 "multi_gpu_hardware_verified": False if world > 1 else None,
-                "arrays_per_cell_update": ARRAYS_PER_STEP,
-                "bytes_per_cell_update_algorithmic": ARRAYS_PER_STEP * esz,
+                "arrays_per_cell_update": round(own_passes, 3),
+                "bytes_per_cell_update_algorithmic": round(own_passes * esz, 2),
+                "arrays_per_cell_update_four_kernel_schedule": ARRAYS_PER_STEP,
+                "step_kernel_list": {k: {"launches_per_step": v["launches_per_step"], "passes": v["algorithmic_passes"]} for k, v in own_kernels.items()} or None,
+                "step_frac_of_peak": fractions,
+                "tm_choice": form_state[1] if not dist_path else None,      # 1 / 0: the rule of vof_step chose k_tm / the chains; -1: the rule does not apply here
+                "gas_share": form_state[3] if not dist_path else None,      # what the rule saw: the share of exact-zero cells of F
                 # two-chain: every kernel of a step as two launches (rows above / below a moving boundary) on two
                 # streams, the lower chain one kernel behind the upper; one-chain: four launches per
                 # step, one after the other (small grids, strips, VOF2D_OVERLAP_HALVES=0)
-                "step_schedule": _batch_form((eng.get_param("overlap_halves"), eng.get_counter("tm_choice"), eng.get_counter("tm_steps"))) if not dist_path else "strips",
+                "step_schedule": _batch_form(form_state[:3]) if not dist_path else "strips",
                 "handle_warm_steps": HANDLE_WARM_STEPS if not dist_path else None,
                 "handle_warm_ms": round(handle_warm_ms, 2) if not dist_path else None},
             # `roofline` = the Poisson Jacobi kernel THE STEP RUNS, k_jacobi_tb (five sweeps per launch): algorithmic bytes =
@@ -836,8 +867,10 @@ def main():
             "step_kernels": step_kernels,
             "strong_scaling_reference_n1": ref8192,
             "speedup_same_grid": speedup,
-            "step_hbm_gbs_algorithmic": ARRAYS_PER_STEP * esz * nx * ny * a.steps / elapsed / 1e9,
-            "step_frac_of_peak_algorithmic": ARRAYS_PER_STEP * esz * nx * ny * a.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+            "step_hbm_gbs_algorithmic": own_passes * esz * nx * ny * a.steps / elapsed / 1e9,
+            "step_frac_of_peak_algorithmic": fractions["own_kernel_list"],
+            "step_frac_of_peak_on_the_four_kernel_schedule": fractions["reference_schedule_19_passes"],
+            "step_frac_of_peak_counter_traffic": fractions["counter_traffic"],
             "kernels_us_dispatch_start_to_stop": kernels_us,
             "courant_violations": violations,
         }
@@ -847,6 +880,8 @@ def main():
         if not dist_path and not a.no_extras:
             try:
                 out["sustained"] = sustained_record(api, nx, ny, a.dtype, a.ic, local, a.jacobi_iters, dt, a.sustained_steps)
+                out["config"]["sustained_ms_per_step"] = round(out["sustained"]["ms_per_step"], 4)     # (in `config` too: the driver's record keeps that object)
+                out["config"]["sustained_steps"] = out["sustained"]["steps"]
             except Exception as exc:
                 out["sustained"] = {"error": str(exc)}
             try:   # what bit-faithful arithmetic costs: the same workload on the FMA-contracted build (own process)

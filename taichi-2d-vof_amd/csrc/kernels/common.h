@@ -12,27 +12,44 @@ namespace vof {
 // records when it started and ended (s_memrealtime, 100 MHz), which shows how evenly a launch's
 // waves finish.  The product build compiles WaveTimer to nothing.
 #ifdef VOF_WAVE_TIMES
-__device__ unsigned long long* vof_wave_times = nullptr;  // [2 * wave] = start, [2 * wave + 1] = end
+__device__ unsigned long long* vof_wave_times = nullptr;  // [2 * wave] = start, [2 * wave + 1] = end; behind them (from 2 * cap): cycles inside barriers, cycles in all
 __device__ int vof_wave_kid = -1;
 __device__ unsigned int vof_wave_cap = 0;
 struct WaveTimer {
-  unsigned long long t0;
+  unsigned long long t0, c0, wait;
   unsigned int wave;
   bool on;
   __device__ __forceinline__ WaveTimer(int kid) {
     on = vof_wave_times != nullptr && vof_wave_kid == kid;
     wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     t0 = on ? wall_clock64() : 0ull;
+    c0 = on ? __builtin_readcyclecounter() : 0ull;
+    wait = 0ull;
+  }
+  // the workgroup barrier of the pair kernels, with the cycles this wave spent inside it
+  __device__ __forceinline__ void barrier() {
+    if (on) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      __syncthreads();
+      wait += __builtin_readcyclecounter() - t;
+    } else {
+      __syncthreads();
+    }
   }
   __device__ __forceinline__ ~WaveTimer() {
     if (on && (threadIdx.x & 63) == 0 && wave < vof_wave_cap) {
       vof_wave_times[2 * wave] = t0;
       vof_wave_times[2 * wave + 1] = wall_clock64();
+      vof_wave_times[2 * vof_wave_cap + 2 * wave] = wait;
+      vof_wave_times[2 * vof_wave_cap + 2 * wave + 1] = __builtin_readcyclecounter() - c0;
     }
   }
 };
 #else
-struct WaveTimer { __device__ __forceinline__ WaveTimer(int) {} };
+struct WaveTimer {
+  __device__ __forceinline__ WaveTimer(int) {}
+  __device__ __forceinline__ void barrier() { __syncthreads(); }
+};
 #endif
 // Diagnostic build only (-DVOF_SHORTCUT_STATS, tools/probes/shortcut_stats.py): how often the wave-level shortcuts of
 // k_momentum and k_transport are taken (one count per wave and row).  The product build compiles VOF_STAT to nothing.
@@ -42,7 +59,17 @@ __device__ unsigned long long vof_stats[16];
 #else
 #define VOF_STAT(k) do { } while (0)
 #endif
-enum : int { WT_MOMENTUM = 0, WT_JACOBI_TB = 3, WT_FCT_X = 5, WT_FCT_Y = 6, WT_JACOBI = 2, WT_TRANSPORT = 12 };  // = KernelId of the runtime
+enum : int { WT_MOMENTUM = 0, WT_JACOBI_TB = 3, WT_FCT_X = 5, WT_FCT_Y = 6, WT_JACOBI = 2, WT_TRANSPORT = 12, WT_JACOBI_PAIR = 13, WT_TM = 14 };  // = KernelId of the runtime
+// Diagnostic build only (tools/probes/pair_bound.py, timing with WRONG values): what a pair kernel's time hangs on.
+// Bits of the ABL template argument of k_jacobi_pair / k_tm; the product instantiates ABL = 0 only.
+enum : int {
+  ABL_FIXED_ROW = 1,   // the first wave loads the same row over and over (L1 / L2 hits instead of the HBM stream)
+  ABL_NO_STORE = 2,    // no global store
+  ABL_PRIO0 = 4,       // NO s_setprio 1 for the first wave of the pair (the product runs it at priority 1)
+  ABL_PRIO1 = 8,       // s_setprio 1 for the second
+  ABL_IDLE1 = 16,      // the second wave only keeps the barriers
+  ABL_PASS0 = 32       // the first wave hands its input rows on without computing
+};
 template <typename T, int V>
 struct Row {  // one row of a wave tile as seen by a lane: j0-1 | j0..j0+V-1 | j0+V
   T l;
@@ -145,6 +172,27 @@ __device__ __forceinline__ void store_buf_nt(const T* base, int lane_off_bytes, 
     typedef unsigned int u2 __attribute__((ext_vector_type(2)));
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, k), r, lane_off_bytes, row_off_bytes, 2 /* nt */);
   }
+}
+// The load that goes with it: the lanes' byte offsets (wave-constant from row to row) in a VGPR, the row's byte offset in
+// an SGPR, the base in the descriptor -- no 64-bit address arithmetic per row and lane (a field below 2 GiB, as above).
+template <typename T, int V>
+__device__ __forceinline__ void load_buf(T (&c)[V], const T* base, int lane_off_bytes, int row_off_bytes, bool nt) {
+  static_assert(sizeof(T) * V == 16 || sizeof(T) * V == 8, "one b128 / b64 load per lane");
+  row_off_bytes = __builtin_amdgcn_readfirstlane(row_off_bytes);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(wave_uniform(const_cast<T*>(base)), 0, kBufSkip, 0x00020000);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  vec_t k;
+  if constexpr (sizeof(T) * V == 16) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 w = nt ? __builtin_amdgcn_raw_buffer_load_b128(r, lane_off_bytes, row_off_bytes, 2) : __builtin_amdgcn_raw_buffer_load_b128(r, lane_off_bytes, row_off_bytes, 0);
+    k = __builtin_bit_cast(vec_t, w);
+  } else {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 w = nt ? __builtin_amdgcn_raw_buffer_load_b64(r, lane_off_bytes, row_off_bytes, 2) : __builtin_amdgcn_raw_buffer_load_b64(r, lane_off_bytes, row_off_bytes, 0);
+    k = __builtin_bit_cast(vec_t, w);
+  }
+#pragma unroll
+  for (int q = 0; q < V; ++q) c[q] = k[q];
 }
 template <typename T, int V>
 __device__ __forceinline__ T left_of(const Row<T, V>& w, int q) { return q == 0 ? w.l : w.c[q - 1]; }
@@ -289,9 +337,25 @@ __device__ __forceinline__ bool tiny_nonzero(float a) {
 // single test whether any numerator left the fast window (tiny, zero, NaN), and only then the
 // full routine.  With a branch per quotient the compiler cannot overlap the dependent fma chains
 // of a lane's V cells.
+struct ColdFlag {   // "the tiny / huge tier ran": a register the caller keeps ...
+  int* p;
+  __device__ __forceinline__ void operator()() const { if (p) *p = 1; }
+};
+struct ColdFlagLds {   // ... or a word in LDS, which costs a store where the tier runs and nothing where it does not
+  typedef __attribute__((address_space(3))) int lds_int;
+  lds_int* p;
+  __device__ __forceinline__ explicit ColdFlagLds(int* q) : p((lds_int*)q) {}
+  __device__ __forceinline__ void operator()() const { *p = 1; }
+};
+template <typename T, int V, bool SMALL_B = false, typename Cold>
+__device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], const T (&b)[V], const T (&y)[V], const Cold& cold);
 template <typename T, int V, bool SMALL_B = false>
 __device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], const T (&b)[V], const T (&y)[V],
                                                int* cold = nullptr /* set to 1 when the tiny / huge tier ran */) {
+  div_by_const_v<T, V, SMALL_B, ColdFlag>(res, a, b, y, ColdFlag{cold});
+}
+template <typename T, int V, bool SMALL_B, typename Cold>
+__device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], const T (&b)[V], const T (&y)[V], const Cold& cold) {
   bool odd = false;
   if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -303,7 +367,7 @@ __device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], con
     if (odd) {   // (lanes holding a tiny non-zero or a huge / non-finite numerator only)
 #pragma unroll
       for (int q = 0; q < V; ++q) res[q] = div_by_const<T, SMALL_B>(a[q], b[q], y[q]);
-      if (cold) *cold = 1;
+      cold();
     }
   } else {
 #pragma unroll
@@ -324,7 +388,7 @@ __device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], con
       if (nonzero) {
 #pragma unroll
         for (int q = 0; q < V; ++q) res[q] = div_by_const<T, SMALL_B>(a[q], b[q], y[q]);
-        if (cold) *cold = 1;
+        cold();
       }
     }
   }

@@ -55,7 +55,7 @@ __device__ __forceinline__ void ring_get(Row<T, V>& w, const T (&row)[64 * V], i
   w.r = row[lane * V + V - (lane < 63 ? 0 : 1)];
 }
 
-template <typename T, int V, bool YFIRST, bool STORE_UV, bool BS>
+template <typename T, int V, bool YFIRST, bool STORE_UV, bool BS, int ABL = 0>
 __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __restrict__ F, T* __restrict__ Fn, int ntf,
                                             const T* __restrict__ us, const T* __restrict__ vs, const T* __restrict__ p,
                                             T* __restrict__ Uo, T* __restrict__ Vo, T* __restrict__ us_out,
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
     return;
   }
   TmRing<T, V>& ring = *reinterpret_cast<TmRing<T, V>*>(smem);
+  WaveTimer wt_(WT_TM);
   const int pair = (int)blockIdx.x - plan_blocks;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: transport, 1: momentum
   const int lane = threadIdx.x & 63;
@@ -85,11 +86,15 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
   const int jhi = c0 + W - HF - 1 < ny ? c0 + W - HF - 1 : ny;
   const int t_lo = ma - 5, t_hi = mb + 8;   // lockstep steps of the pair
   auto rowptr = [&](const T* base, int r) {
+    if constexpr ((ABL & ABL_FIXED_ROW) != 0) r = ma;
     const int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
     return base + at(g, rc, j0);
   };
 
   if (role == 0) {
+    // the transport wave is the one the momentum wave waits for: priority 1 (4096^2 fp64: 314 -> 299 us y first, 327 -> 305 x first;
+    // the momentum wave instead: 314 / 333).  ABL_PRIO0 of the diagnostic build = without it.
+    if constexpr ((ABL & ABL_PRIO0) == 0) __builtin_amdgcn_s_setprio(1);
     // ------------------------------------------------------------------ transport march (k_transport's, rows tra .. trb)
     const int tra = ma - 3, trb = mb + 3;
     FctXPipe<T, V> pipe;
@@ -140,6 +145,16 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
           load_s<T, V>(usnx, rowptr(us, r + 1));
           load_s<T, V>(vsnx, rowptr(vs, r + 1));
           load_c<T, V>(pnx, rowptr(p, r + 1));
+        }
+        if constexpr ((ABL & ABL_PASS0) != 0) {   // timing only: the loaded rows go on as they are
+#pragma unroll
+          for (int q = 0; q < V; ++q) Fr[q] += pr[q] * (T)0;
+          ring_put<T, V>(ring.u[r & 7], lane, ur);
+          ring_put<T, V>(ring.v[r & 7], lane, vr);
+          ring_put<T, V>(ring.f[(r - 3) & 7], lane, Fr);
+          if (r - 3 >= ma && r - 3 <= mb && !(ABL & ABL_NO_STORE)) store_s<T, V>(Fn + at(g, r - 3, j0), Fr, j0, jlo, jhi);
+          wt_.barrier();
+          continue;
         }
         int cls = 2;
         {
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
           }
           ring_put<T, V>(ring.u[r & 7], lane, ur);
           ring_put<T, V>(ring.v[r & 7], lane, vr);
-          if (STORE_UV && own) {
+          if (STORE_UV && own && !(ABL & ABL_NO_STORE)) {
             store_s<T, V>(Uo + at(g, r, j0), ur, j0, jlo, jhi);
             store_s<T, V>(Vo + at(g, r, j0), vr, j0, jlo, jhi == ny ? ny + 1 : jhi);
             if (r == nx) {
@@ -242,9 +257,9 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
           }
         }
         ring_put<T, V>(ring.f[io & 7], lane, out);
-        if (io >= ma && io <= mb) store_s<T, V>(Fn + at(g, io, j0), out, j0, jlo, jhi);
+        if (io >= ma && io <= mb && !(ABL & ABL_NO_STORE)) store_s<T, V>(Fn + at(g, io, j0), out, j0, jlo, jhi);
       }
-      __syncthreads();
+      wt_.barrier();
     }
     if (__any(viol != 0)) {
       unsigned int tot = viol;
@@ -256,6 +271,11 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
   }
 
   // -------------------------------------------------------------------- momentum march (k_momentum's, rows ma .. mb)
+  if constexpr ((ABL & ABL_PRIO1) != 0) __builtin_amdgcn_s_setprio(1);
+  if constexpr ((ABL & ABL_IDLE1) != 0) {
+    for (int t = t_lo; t <= t_hi; ++t) wt_.barrier();
+    return;
+  }
   const T dt = c.dt, dxi = c.dxi, dyi = c.dyi, dxi2 = c.dxi2, dyi2 = c.dyi2;
   bool dom[V];
 #pragma unroll
@@ -394,7 +414,9 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
         us2[q] = (okP && i >= 2 && dom[q]) ? ou : (T)0;
         vs2[q] = (okP && j >= 2 && j <= ny) ? ov : (T)0;
       }
-      if constexpr (BS) {
+      if constexpr ((ABL & ABL_NO_STORE) != 0) {
+        asm volatile("" :: "v"(us2[0]), "v"(us2[V - 1]), "v"(vs2[0]), "v"(vs2[V - 1]));
+      } else if constexpr (BS) {
         const bool rowok = i >= ma && i <= mb;
         const int vo = rowok ? voff_st : kBufSkip;
         const int so = rowok ? (int)((int64_t)(i - g.row_lo) * g.pitch * (int64_t)sizeof(T)) : 0;
@@ -415,7 +437,9 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
           out[q] = div_by_const_inrange<T>(rho3[q], c.dt, c.inv_dt) *
                    ((us2[q] - us3[q]) * c.dxi + (vright - vs3[q]) * c.dyi);
         }
-        if constexpr (BS)
+        if constexpr ((ABL & ABL_NO_STORE) != 0)
+          asm volatile("" :: "v"(out[0]), "v"(out[V - 1]));
+        else if constexpr (BS)
           store_buf_nt<T, V>(rhs_tile, (i3 >= ma && i3 <= mb) ? voff_st : kBufSkip,
                              (i3 >= ma && i3 <= mb) ? (int)((int64_t)(i3 - g.row_lo) * g.pitch * (int64_t)sizeof(T)) : 0, out);
         else
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
       u3 = u2; u2 = u1;
       v3 = v2; v2 = v1;
     }
-    __syncthreads();
+    wt_.barrier();
   }
 }
 

@@ -476,4 +476,15 @@ __global__ __launch_bounds__(256) void k_correct(Geom g, Consts<T> c, const T* _
   }
 }
 
+// cells of the computable rows whose F is an exact zero (the batch-form rule of vof_step: one look at the state per handle)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gas_cells(Geom g, const T* __restrict__ F, unsigned long long* __restrict__ out) {
+  unsigned int n = 0;
+  for (int i = g.ilo + (int)blockIdx.x; i <= g.ihi; i += (int)gridDim.x)
+    for (int j = 1 + (int)threadIdx.x; j <= g.ny; j += 256) n += F[at(g, i, j)] == (T)0 ? 1u : 0u;
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) n += __shfl_down(n, sft, 64);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, (unsigned long long)n);
+}
+
 }  // namespace vof

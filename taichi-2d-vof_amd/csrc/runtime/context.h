@@ -163,7 +163,7 @@ struct vof2d_ctx {
   // F / twin pair and the step parity are back where they started): a graph launch leaves ~9 us of idle queue
   // behind it, which one launch per step pays every step (vof_step)
   static constexpr int kStepBatches = 3;
-  static constexpr int kTuneBatch = 1;     // the batch size the two forms are timed with (fuse_tm = -1)
+  static constexpr int kTuneBatch = 1;     // the batch size the two forms are timed with (fuse_tm = -2)
   // (the k_tm form has one plain k_momentum and one plain k_transport per batch: 4096^2 0.5256 ms/step in batches of 8, 0.5193 of 16,
   // 0.5178 of 32, 0.5346 of 4; knob "batch_steps" sets the first)
   int step_batch[kStepBatches] = {16, 8, 2};
@@ -172,9 +172,12 @@ struct vof2d_ctx {
   // boundary that moves up by kHalvesDrift rows from kernel to kernel, the upper chain on `stream`, the lower on
   // `chain_streams`; a lower launch waits for the upper launch of the kernel before it only (enqueue_steps_halves)
   // knob "fuse_tm": the batch graphs run k_transport + the next step's k_momentum as one kernel (k_tm, kernels/fused_tm.h):
-  // 0 never, 1 wherever the schedule allows, -1 (default) on large fp64 grids after timing both forms on the handle's
-  // own data: four 8-step batches alternate between the forms, the faster one stays (vof_step)
+  // 0 never, 1 wherever the schedule allows, -1 (default) on large fp64 grids by a rule on the state (the share of gas
+  // cells: decide_batch_form_by_rule), -2 (exploration) after timing both forms on the handle's own data: four 8-step
+  // batches alternate between the forms, the faster one stays (vof_step)
   int fuse_tm = -1;
+  double gas_share = -1.0;   // what the rule saw (get_param "gas_share")
+  bool tm_broken = false;    // the k_tm batch graphs could not be captured: the other form stays
   int jpair = 1;             // knob "jacobi_pair": the k_tm batch graphs run each two five-sweep launches as one k_jacobi_pair launch
   int jpair_rows = 0;        // rows per pair chunk (0 = one residency round of pairs)
   bool jpair_active = false; // the launches being enqueued are k_jacobi_pair's (tb_plan describes their geometry)

@@ -196,13 +196,16 @@ inline bool tm_eligible(const vof2d_ctx* h) {
   return h->fuse_tm != 0 && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 && h->d.jacobi_iters % 5 == 0 &&
          h->d.jacobi_iters / 5 % 2 == 0 && h->g.nx >= 16;
 }
-// fuse_tm = -1: the handle times both forms where k_tm has a chance -- large fp64 grids (tools/probes/halves_sweep.py,
-// ms/step one chain / chains / k_tm: 4096^2 dam-break 0.601 / 0.576 / 0.547, 8192^2 2.27 / 2.31 / 1.93, but 4096^2
-// rising bubble 0.682 / 0.612 / 0.808 -- mostly liquid: the pair is bound by its instruction issue --, 4096^2 fp32
-// 0.364 / 0.337 / 0.361, 3072^2 0.351 / 0.346 / 0.346, 2048^2 0.168 / - / 0.188)
-inline bool tm_auto(const vof2d_ctx* h) {
-  return h->fuse_tm < 0 && tm_eligible(h) && h->d.dtype == VOF_F64 && (long)h->g.nx * h->g.ny >= 6000000L && h->g.nx >= 2048;   // (the sizes that run chains: below, neither form pays)
+// Where k_tm has a chance at all -- large fp64 grids (tools/probes/halves_sweep.py, ms/step one chain / chains / k_tm, round 4:
+// 4096^2 dam-break 0.601 / 0.576 / 0.547, 8192^2 2.27 / 2.31 / 1.93, but 4096^2 rising bubble 0.682 / 0.612 / 0.808 -- mostly
+// liquid --, 4096^2 fp32 0.364 / 0.337 / 0.361, 3072^2 0.351 / 0.346 / 0.346, 2048^2 0.168 / - / 0.188) -- the form is chosen by
+// a rule on the state (fuse_tm = -1, the default: decide_batch_form_by_rule) or, for exploration, by timing both (fuse_tm = -2).
+constexpr double kTmGasShare = 0.5;   // k_tm from this share of exact-zero cells of F on
+inline bool tm_size_ok(const vof2d_ctx* h) {
+  return tm_eligible(h) && h->d.dtype == VOF_F64 && (long)h->g.nx * h->g.ny >= 6000000L && h->g.nx >= 2048;   // (the sizes that run chains: below, neither form pays)
 }
+inline bool tm_by_rule(const vof2d_ctx* h) { return h->fuse_tm == -1 && tm_size_ok(h); }
+inline bool tm_auto(const vof2d_ctx* h) { return h->fuse_tm == -2 && tm_size_ok(h); }
 // chains: two; three from 32 M cells (8192^2: 2.30 ms/step in one chain, 2.29 in two, 2.16 in three, 2.17 in four; 4096^2: 0.595 / 0.574 /
 // 0.566 / 0.579 inside the front, 0.582 / 0.562 / 0.565 / 0.583 behind it); knob values >= 2 force a count
 inline int halves_chains(const vof2d_ctx* h) {
@@ -246,7 +249,7 @@ bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
   for (int p = 1; p < P; ++p) ok = ok && hipStreamWaitEvent(st[p], ev_fork, 0) == hipSuccess;
   int s[8];                                                         // chain p produces rows (s[p - 1], s[p]]
   for (int p = 0; p < P - 1; ++p) s[p] = (int)((long)(p + 1) * nx / P) + (total * kHalvesDrift) / 2;
-  int n = 0;
+  int n = 0, n_lastjac = 0;
   auto all = [&](auto&& fn) {
     for (int p = 0; p < P; ++p) {
       if (p > 0 && n > 0) ok = ok && hipStreamWaitEvent(st[p], ev_done[(p - 1) * total + n - 1], 0) == hipSuccess;
@@ -265,14 +268,23 @@ bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
     const int par = (int)(istep & 1);
     // The first chain's launch of k_momentum carries the planner block of the step's Jacobi launches (tb_make_plan):
     // it overwrites the plan the previous step's launches read and reads the hit masks they reported, so it waits
-    // for the last chain to be through them -- the one edge that points up the chains.
-    if (k > 0) ok = ok && hipStreamWaitEvent(st[0], ev_plan[k - 1], 0) == hipSuccess;
+    // for EVERY other chain to be through them -- the edges that point up the chains (chain p < P - 1: the event behind
+    // its last Jacobi launch; the last chain: ev_plan) ...
+    if (k > 0) {
+      for (int p = 1; p < P - 1; ++p) ok = ok && hipStreamWaitEvent(st[0], ev_done[p * total + n_lastjac], 0) == hipSuccess;
+      ok = ok && hipStreamWaitEvent(st[0], ev_plan[k - 1], 0) == hipSuccess;
+    }
+    const int n_mom = n;
     all([&](int a, int b, bool first) { L<T>::momentum(h, true, first ? par : -1, a, b); });
+    // ... and no chain reads the plan before the planner of ITS step has written it: chain 1's first Jacobi launch is
+    // ordered behind chain 0's k_momentum by the chain edge, chains 2 .. only behind chain 1's k_momentum
+    for (int p = 2; p < P; ++p) ok = ok && hipStreamWaitEvent(st[p], ev_done[n_mom], 0) == hipSuccess;
     int cur = fP, oth = fPT;
     for (int j = 0; j < nj; ++j) {
       all([&](int a, int b, bool) { L<T>::template jacobi_tb<5>(h, cur, oth, par, a, b); });
       const int t = cur; cur = oth; oth = t;
     }
+    n_lastjac = n - 1;
     ok = ok && hipEventRecord(ev_plan[k], st[P - 1]) == hipSuccess;
     all([&](int a, int b, bool) {
       const RowRanges rr{{a, 1, 1}, {b, 0, 0}, {L<T>::transport_rows(h), 1, 1}};
@@ -343,6 +355,7 @@ int ensure_ok(vof2d_ctx* h) {
 
 #define DISPATCH_T(h, expr_d, expr_f) \
   do { if ((h)->d.dtype == VOF_F64) { expr_d; } else { expr_f; } } while (0)
+#define DISPATCH_B(h, expr_d, expr_f) ((h)->d.dtype == VOF_F64 ? (expr_d) : (expr_f))
 
 // true if the next vof_step runs the fused full-domain schedule (k_momentum, 2 x k_jacobi_tb,
 // k_transport) that leaves the ghost cells virtual
@@ -387,7 +400,7 @@ void destroy_graphs(vof2d_ctx* h) {
     for (int k = 0; k < 2; ++k)
       for (int o = 0; o < 2; ++o)
         if (h->gbatch_tm[b][k][o]) { (void)hipGraphExecDestroy(h->gbatch_tm[b][k][o]); h->gbatch_tm[b][k][o] = nullptr; }
-  h->tune_n = 0; h->tune_age = 0; h->tm_decided = false; h->tune_ms[0] = h->tune_ms[1] = 0.f;   // (a changed knob changes what is being compared)
+  h->tune_n = 0; h->tune_age = 0; h->tm_decided = false; h->tm_broken = false; h->tune_ms[0] = h->tune_ms[1] = 0.f;   // (a changed knob changes what is being compared)
   for (int b = 0; b < vof2d_ctx::kStepBatches; ++b) h->halves_captured[b] = false;
   h->batching = true;   // (a parameter change may be what a capture tripped over: try again)
   for (int k = 0; k < 5; ++k)

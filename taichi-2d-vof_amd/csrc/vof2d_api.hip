@@ -16,6 +16,9 @@
 #include "runtime/schedule.h"
 #include "runtime/comm.h"
 #include "runtime/selftest.h"
+#ifdef VOF_WAVE_TIMES
+#include "runtime/diag.h"
+#endif
 
 // =============================================================== C ABI
 extern "C" {
@@ -146,6 +149,7 @@ int vof_set_init_F(vof2d_handle h, int32_t ic) {
   settle_ghosts(h);
   DISPATCH_T(h, L<double>::init_F(h, ic), L<float>::init_F(h, ic));
   h->f_ghosts_dirty = true;
+  if (h->fuse_tm == -1) h->tm_decided = false;   // (the batch-form rule looks at the new F)
   return ensure_ok(h);
 }
 int vof_set_BC(vof2d_handle h) {
@@ -280,9 +284,33 @@ static void build_step_batches(vof2d_ctx* h, int variant /* 0: chains or the pla
     for (int b = 0; b < vof2d_ctx::kStepBatches; ++b)
       for (int k = 0; k < 4; ++k)
         if (GB[b][k >> 1][k & 1]) { (void)hipGraphExecDestroy(GB[b][k >> 1][k & 1]); GB[b][k >> 1][k & 1] = nullptr; }
-    h->batching = false;
-    if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] step batches could not be captured: one graph launch per step\n");
+    // the k_tm form failing leaves the other form's batch graphs in use; only when those fail is it one graph launch per step
+    if (variant) h->tm_broken = true; else h->batching = false;
+    if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] step batches (%s) could not be captured: %s\n", variant ? "k_tm form" : "chains / plain",
+                                       variant ? "the other form stays" : "one graph launch per step");
   }
+}
+
+// Which form of the batch graphs a large fp64 full domain runs (knob fuse_tm = -1, the default): a RULE on the state, so
+// that two handles on the same data always run the same schedule.  k_tm + k_jacobi_pair win where most rows are cheap for
+// the transport pipeline (gas: the x pipeline bypasses itself, the y stage is skipped) and lose where they are not -- 4096^2
+// dam-break (5/6 gas) 0.49 against 0.56 ms/step for the chains, 4096^2 rising bubble (2 % gas) 0.81 against 0.61 -- so the
+// rule is the share of exact-zero cells of F when the handle first batches steps (and again after F was replaced from
+// outside): one small kernel and one 8-byte read-back, where the graphs are being captured anyway.
+static int decide_batch_form_by_rule(vof2d_ctx* h) {
+  unsigned long long* cnt = h->d_courant + 3;
+  HIPCHK(h, hipMemsetAsync(cnt, 0, sizeof(*cnt), h->stream));
+  const unsigned blocks = (unsigned)(h->g.ihi - h->g.ilo + 1 < 2048 ? h->g.ihi - h->g.ilo + 1 : 2048);
+  if (h->d.dtype == VOF_F64) hipLaunchKernelGGL(k_gas_cells<double>, dim3(blocks), dim3(256), 0, h->stream, h->g, (const double*)F_<double>(h, fF), cnt);
+  else hipLaunchKernelGGL(k_gas_cells<float>, dim3(blocks), dim3(256), 0, h->stream, h->g, (const float*)F_<float>(h, fF), cnt);
+  unsigned long long n = 0;
+  HIPCHK(h, hipMemcpyAsync(&n, cnt, sizeof(n), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->gas_share = (double)n / ((double)(h->g.ihi - h->g.ilo + 1) * (double)h->g.ny);
+  h->tm_choice = h->gas_share >= kTmGasShare ? 1 : 0;
+  h->tm_decided = true;
+  if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] batch form by rule: %.3f of the cells are gas -> %s\n", h->gas_share, h->tm_choice ? "k_tm" : "chains / plain");
+  return VOF_OK;
 }
 
 int vof_step(vof2d_handle h, int64_t nsteps) {
@@ -314,7 +342,13 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       // first times both on its own data -- four 8-step batches, alternating -- and keeps the faster (tm_auto).
       int variant = (h->fuse_tm > 0 && tm_eligible(h)) ? 1 : 0;
       bool timed = false;
-      if (tm_auto(h)) {
+      if (tm_by_rule(h)) {
+        if (!h->tm_decided) {
+          const int rc = decide_batch_form_by_rule(h);
+          if (rc) { h->istep -= 1; return rc; }
+        }
+        variant = h->tm_choice;
+      } else if (tm_auto(h)) {   // fuse_tm = -2 (exploration): both forms timed on the handle's own data
         if (h->tune_n == 4) {
           bool done = hipEventSynchronize(h->tune_ev[7]) == hipSuccess;
           for (int k = 0; k < 4 && done; ++k) {
@@ -337,8 +371,12 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
         }
         else { variant = h->tm_choice; h->tune_age += 1; }
       }
+      if (variant && h->tm_broken) variant = 0;
+      if (h->batching && !(variant ? h->gbatch_tm : h->gbatch)[0][par][h->fld[fF] == h->f_home ? 0 : 1]) {
+        build_step_batches(h, variant);
+        if (variant && h->tm_broken) { variant = 0; timed = false; if (h->batching && !h->gbatch[0][par][h->fld[fF] == h->f_home ? 0 : 1]) build_step_batches(h, 0); }
+      }
       auto& GB = variant ? h->gbatch_tm : h->gbatch;
-      if (h->batching && !GB[0][par][h->fld[fF] == h->f_home ? 0 : 1]) build_step_batches(h, variant);
       const int ori = h->fld[fF] == h->f_home ? 0 : 1;
       bool batched = false;
       for (int b = timed ? vof2d_ctx::kTuneBatch : 0; b < vof2d_ctx::kStepBatches && !batched; ++b) {   // (while the forms are being timed: batches of the timed size)
@@ -347,13 +385,13 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
         const bool time_it = timed && b == vof2d_ctx::kTuneBatch && h->batching;
         if (time_it) {
           for (int k = 0; k < 2; ++k)
-            if (!h->tune_ev[2 * h->tune_n + k] && hipEventCreate(&h->tune_ev[2 * h->tune_n + k]) != hipSuccess) return fail(h, VOF_EHIP, "hipEventCreate");
-          HIPCHK(h, hipEventRecord(h->tune_ev[2 * h->tune_n], h->stream));
+            if (!h->tune_ev[2 * h->tune_n + k] && hipEventCreate(&h->tune_ev[2 * h->tune_n + k]) != hipSuccess) { h->istep -= 1; return fail(h, VOF_EHIP, "hipEventCreate"); }
+          if (hipEventRecord(h->tune_ev[2 * h->tune_n], h->stream) != hipSuccess) { h->istep -= 1; return fail(h, VOF_EHIP, "hipEventRecord"); }
         }
-        HIPCHK(h, hipGraphLaunch(GB[b][par][ori], h->stream));
+        if (hipGraphLaunch(GB[b][par][ori], h->stream) != hipSuccess) { h->istep -= 1; return fail(h, VOF_EHIP, "hipGraphLaunch of a step batch"); }
         if (time_it) {
-          HIPCHK(h, hipEventRecord(h->tune_ev[2 * h->tune_n + 1], h->stream));
-          h->tune_n += 1;
+          if (hipEventRecord(h->tune_ev[2 * h->tune_n + 1], h->stream) == hipSuccess) h->tune_n += 1;
+          else (void)hipGetLastError();   // (the batch ran: this timing is lost, the steps are not)
         }
         h->istep += K - 1;
         s += K - 1;
@@ -536,7 +574,7 @@ int vof_set_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, const
   if (id < 0) return fail(h, VOF_EINVAL, "unknown field name");
   int rc = copy_rows_host(h, id, g0, g1, const_cast<void*>(src), nbytes, false);
   if (rc == VOF_OK && id == fF) rc = copy_rows_host(h, fF2, g0, g1, const_cast<void*>(src), nbytes, false);
-  if (id == fF || id == fF2) h->f_ghosts_dirty = true;
+  if (id == fF || id == fF2) { h->f_ghosts_dirty = true; if (h->fuse_tm == -1) h->tm_decided = false; }
   if (id == fU || id == fV) h->uv_ghosts_dirty = true;
   return rc;
 }
@@ -584,7 +622,7 @@ int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t 
                                reinterpret_cast<char*>(src->fld[fF]) + off_s, bytes, hipMemcpyDeviceToDevice,
                                dst->stream));
   if (dst->g.wall_lo && dst->g.wall_hi) {  // a full domain: the rows' neighbours' ghost cells may no longer mirror them
-    if (id == fF) dst->f_ghosts_dirty = true;
+    if (id == fF) { dst->f_ghosts_dirty = true; if (dst->fuse_tm == -1) dst->tm_decided = false; }
     if (id == fU || id == fV) dst->uv_ghosts_dirty = true;
   }
   return VOF_OK;
@@ -689,6 +727,7 @@ int vof_get_param(vof2d_handle h, const char* name, double* value) {
   if (!strcmp(name, "jacobi_tb")) { *value = (double)h->tb; return VOF_OK; }
   if (!strcmp(name, "jacobi_tb_adapt")) { *value = (double)h->tb_adapt; return VOF_OK; }
   if (!strcmp(name, "overlap_halves")) { *value = halves_eligible(h, h->step_batch[vof2d_ctx::kTuneBatch]) ? 1.0 : 0.0; return VOF_OK; }   // effective
+  if (!strcmp(name, "gas_share")) { *value = h->gas_share; return VOF_OK; }   // share of exact-zero cells of F the batch-form rule saw (-1: not looked yet)
   if (!strcmp(name, "fuse_transport")) {  // 1 if vof_step runs both FCT sweeps as one kernel on this handle
     *value = (h->g.wall_lo && h->g.wall_hi && h->fuse_transport) ? 1.0 : 0.0;
     return VOF_OK;
@@ -719,8 +758,8 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
     *value = h->tm_steps;
     return VOF_OK;
   }
-  if (!strcmp(name, "tm_choice")) {   // -1: the forms are still being timed (or never will be), 0 / 1: the form that stayed
-    *value = (tm_auto(h) && h->tm_decided) ? h->tm_choice : -1;
+  if (!strcmp(name, "tm_choice")) {   // -1: not decided (yet, or the knob decides), 0 / 1: the form the rule (fuse_tm = -1) or the timing (-2) chose
+    *value = ((tm_auto(h) || tm_by_rule(h)) && h->tm_decided) ? h->tm_choice : -1;
     return VOF_OK;
   }
   if (!strcmp(name, "halves_steps")) {   // steps replayed from batch graphs in the two-chain form (enqueue_steps_halves)
@@ -767,10 +806,13 @@ int vof_profile_steps(vof2d_handle h, int64_t nsteps) {
     int batch = 0;
     // A handle whose batch graphs run the k_tm form is profiled in that form: the same launch sequence, eagerly, every
     // launch between its own event pair (k_momentum, K x k_jacobi_pair / 2 K x k_jacobi_tb, K - 1 x k_tm, k_transport).
-    const bool tm_form = ((h->fuse_tm > 0 && tm_eligible(h)) || (tm_auto(h) && h->tm_decided && h->tm_choice == 1)) &&
+    const bool tm_form = ((h->fuse_tm > 0 && tm_eligible(h)) || ((tm_auto(h) || tm_by_rule(h)) && h->tm_decided && h->tm_choice == 1)) && !h->tm_broken &&
                          !h->f_ghosts_dirty && !h->uv_ghosts_dirty && step_leaves_ghosts_virtual(h) && nsteps - done >= 2;
     if (tm_form) {
-      const int K = nsteps - done >= 8 ? 8 : 2;
+      // (1 + K x (Jacobi launches + 1) launches, each with its own event pair out of the pool)
+      const int per_tm_step = 1 + (DISPATCH_B(h, L<double>::jacobi_pair_ok(h), L<float>::jacobi_pair_ok(h)) ? h->d.jacobi_iters / 10 : h->d.jacobi_iters / 5);
+      const int K = (nsteps - done >= 8 && 1 + 8 * per_tm_step <= vof2d_ctx::kMaxTimed) ? 8 : 2;
+      if (1 + K * per_tm_step > vof2d_ctx::kMaxTimed) { h->timed = -1; return fail(h, VOF_ESTATE, "a k_tm batch of two steps has more launches than the profiling event pool"); }
       DISPATCH_T(h, enqueue_steps_tm<double>(h, h->istep + 1, K), enqueue_steps_tm<float>(h, h->istep + 1, K));
       h->istep += K;
       h->ghosts_virtual = true;
@@ -830,20 +872,47 @@ extern "C" int vof_debug_wave_times(vof2d_handle h, int32_t kid, uint64_t* out, 
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (out) {
     if (!buf || cap > bufcap) return VOF_EINVAL;
+    if (kid == -2) {   // the second half: cycles inside barriers, cycles in all (the pair kernels)
+      if (cap != bufcap) return VOF_EINVAL;
+      HIPCHK(h, hipMemcpy(out, buf + 2 * (size_t)bufcap, (size_t)cap * 16, hipMemcpyDeviceToHost));
+      return VOF_OK;
+    }
     HIPCHK(h, hipMemcpy(out, buf, (size_t)cap * 16, hipMemcpyDeviceToHost));
     return VOF_OK;
   }
   if (cap > bufcap) {
     if (buf) (void)hipFree(buf);
-    HIPCHK(h, hipMalloc(&buf, (size_t)cap * 16));
+    HIPCHK(h, hipMalloc(&buf, (size_t)cap * 32));   // start / end stamps, then (barrier cycles, all cycles) per wave
     bufcap = cap;
   }
-  HIPCHK(h, hipMemset(buf, 0, (size_t)bufcap * 16));
+  HIPCHK(h, hipMemset(buf, 0, (size_t)bufcap * 32));
   int k = kid;
   HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(vof::vof_wave_times), &buf, sizeof(buf)));
   HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(vof::vof_wave_kid), &k, sizeof(k)));
   HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(vof::vof_wave_cap), &bufcap, sizeof(bufcap)));
   return VOF_OK;
+}
+// Diagnostic build only (tools/probes/pair_bound.py): `reps` launches of one pair kernel on the handle's current state
+// between one event pair -- k_jacobi_pair (which = 0; p, rhs -> pt, no swap) or k_tm (1: y first, 2: x first; F, u*, v*, p ->
+// the twin of F, the second u* / v* pair, rhs: all scratch outside a batch) -- in the ablated form `abl` (ABL_* bits,
+// kernels/common.h; wrong values, the state the steps run on is not touched).  plan != 0: k_jacobi_pair on the step's work plan.
+extern "C" int vof_debug_time_kernel(vof2d_handle h, int32_t which, int32_t abl, int32_t plan, int32_t reps, float* avg_us) {
+  if (!h || !avg_us || reps < 1 || h->d.dtype != VOF_F64 || !buffer_stores_ok(h)) return VOF_EINVAL;
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  for (int r = 0; r < reps; ++r) {
+#define ABL_CASE(a) case a: if (which == 0) dbg_pair<a>(h, plan); else if (which == 1) dbg_tm<true, a>(h); else dbg_tm<false, a>(h); break;
+    switch (abl) {
+      ABL_CASE(0) ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(32) ABL_CASE(48) ABL_CASE(19) ABL_CASE(35)
+      default: return fail(h, VOF_EINVAL, "ablation not instantiated");
+    }
+#undef ABL_CASE
+  }
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_us = 1e3f * ms / (float)reps;
+  return ensure_ok(h);
 }
 #endif
 int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep) {

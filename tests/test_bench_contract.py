@@ -30,6 +30,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert rf["algorithmic_bytes_per_launch"] == 3 * 8 * 512 * 512 and rf["sweeps_per_launch"] == 5
     assert "traffic" in rf and isinstance(rf["traffic_note"], str) and rf["duration_source"].startswith("in-situ profile") and "14 steps" in rf["duration_source"]
     assert d["config"]["step_schedule"] == "one-chain batch graphs"          # (512^2: chains start at 6 M cells)
+    cfg = d["config"]                              # the step's own kernel list: 6 + 2 x 3 + 7 passes, and the three fractions side by side
+    assert abs(cfg["arrays_per_cell_update"] - 19.0) < 1e-6 and abs(cfg["bytes_per_cell_update_algorithmic"] - 152.0) < 1e-6
+    assert set(cfg["step_kernel_list"]) == {"k_momentum", "k_jacobi_tb", "k_transport"} and cfg["step_kernel_list"]["k_jacobi_tb"]["launches_per_step"] == 2.0
+    fr = cfg["step_frac_of_peak"]
+    assert abs(fr["own_kernel_list"] - d["step_frac_of_peak_algorithmic"]) < 1e-12 and abs(fr["own_kernel_list"] - fr["reference_schedule_19_passes"]) < 1e-9
+    assert abs(fr["own_kernel_list"] - 19 * 8 * 512 * 512 / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    assert "counter_traffic" in fr and isinstance(fr["counter_traffic_note"], str)
+    assert cfg["tm_choice"] == -1 and cfg["sustained_ms_per_step"] > 0 and cfg["sustained_steps"] == 200   # (the rule applies from 6 M cells)
+    assert d["courant_violations"] == 0
     assert abs(rf["us_per_launch"] - d["step_kernels"]["k_jacobi_tb"]["us_per_launch_dispatch"]) < 1e-9
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"]
     one = rf["north_star_single_sweep"]            # the single-sweep kernel of the north star's wording: a sub-record
@@ -201,21 +210,25 @@ def test_traffic_is_quoted_only_for_the_kernel_sources_it_was_measured_on(tmp_pa
 
 @pytest.mark.gpu
 def test_bench_reports_the_form_the_handle_keeps():
-    """A large fp64 grid: the handle times its two batch forms and keeps one (config.step_schedule); if that is the k_tm
-    form, `roofline` names k_tm (8 algorithmic passes), carries the Jacobi kernel of the step and the record of the four
-    classic kernels one at a time; else it is that record itself."""
+    """A large fp64 grid: the handle chooses its batch form by a rule on the state (a dam-break: k_tm + k_jacobi_pair;
+    config.step_schedule, config.tm_choice, config.gas_share); `roofline` then names k_tm (8 algorithmic passes), carries
+    the Jacobi kernel of the step and the record of the four classic kernels one at a time, and config's per-step byte
+    count is the kept form's own kernel list (launches per step x passes), not the four-kernel schedule's 19 passes."""
     d, _ = _run_bench(["--nx", "3072", "--steps", "16", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--no-scaling-reference",
                     "--profile-steps", "24"])
     cfg, rf = d["config"], d["roofline"]
-    assert cfg["handle_warm_steps"] == 41 and cfg["handle_warm_ms"] > 0
+    assert cfg["handle_warm_steps"] == 19 and cfg["handle_warm_ms"] > 0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["bound"] == "hbm"
-    if cfg["step_schedule"].startswith("k_tm"):
-        assert rf["kernel"] == "k_tm" and rf["algorithmic_passes"] == 8 and rf["algorithmic_bytes_per_launch"] == 8 * 8 * 3072 * 3072
-        assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 1e-3 * rf["achieved"]   # (us rounded to 0.01)
-        run = d["step_kernels_as_run"]
-        assert set(run) >= {"k_tm", "k_jacobi_pair"} and abs(run["k_jacobi_pair"]["launches_per_step"] - 1.0) < 1e-9
-        assert 0.8 <= run["k_tm"]["launches_per_step"] < 1.0 and rf["jacobi_kernel_of_the_step"]["sweeps_per_launch"] == 10
-        assert rf["one_kernel_at_a_time"]["kernel"] == "k_jacobi_tb" and 0 < rf["one_kernel_at_a_time"]["frac"] < 1
-    else:
-        assert rf["kernel"] == "k_jacobi_tb" and not d["step_kernels_as_run"]
+    assert cfg["step_schedule"].startswith("k_tm") and cfg["tm_choice"] == 1 and 0.8 < cfg["gas_share"] < 0.85
+    assert rf["kernel"] == "k_tm" and rf["algorithmic_passes"] == 8 and rf["algorithmic_bytes_per_launch"] == 8 * 8 * 3072 * 3072
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 1e-3 * rf["achieved"]   # (us rounded to 0.01)
+    run = d["step_kernels_as_run"]
+    assert set(run) >= {"k_tm", "k_jacobi_pair"} and abs(run["k_jacobi_pair"]["launches_per_step"] - 1.0) < 1e-9
+    assert 0.8 <= run["k_tm"]["launches_per_step"] < 1.0 and rf["jacobi_kernel_of_the_step"]["sweeps_per_launch"] == 10
+    assert rf["one_kernel_at_a_time"]["kernel"] == "k_jacobi_tb" and 0 < rf["one_kernel_at_a_time"]["frac"] < 1
+    own = sum(v["launches_per_step"] * v["algorithmic_passes"] for v in run.values())
+    assert abs(cfg["arrays_per_cell_update"] - own) < 2e-3 and 11.0 < own < 13.0 and cfg["arrays_per_cell_update_four_kernel_schedule"] == 19
+    assert set(cfg["step_kernel_list"]) == set(run)
+    fr = cfg["step_frac_of_peak"]
+    assert abs(fr["own_kernel_list"] * 19.0 / own - fr["reference_schedule_19_passes"]) < 1e-9 and fr["own_kernel_list"] == d["step_frac_of_peak_algorithmic"]
     assert rf["north_star_single_sweep"]["kernel"] == "k_jacobi"

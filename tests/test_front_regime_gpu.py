@@ -72,8 +72,8 @@ def test_plan_on_equals_plan_off_at_baseline_sizes(hip_api, n, steps, checks, dt
     on = engine(hip_api, n, n, "f64", "f32", ic=1, **kw)
     off = engine(hip_api, n, n, "f64", "f32", ic=1, **kw)
     off.set_param("jacobi_tb_adapt", 0)
-    off.set_param("overlap_halves", 0)               # (`on` runs the default at these sizes: chains of launches or k_tm,
-    off.set_param("fuse_tm", 0)                      #  whichever the handle finds faster; `off` the plain four-kernel sequence)
+    off.set_param("overlap_halves", 0)               # (`on` runs the default at these sizes -- by the rule of vof_step, k_tm +
+    off.set_param("fuse_tm", 0)                      #  k_jacobi_pair on a dam-break --, `off` the plain four-kernel sequence)
     active = 0
     for st in checks:
         while on.istep < st:
@@ -88,8 +88,9 @@ def test_plan_on_equals_plan_off_at_baseline_sizes(hip_api, n, steps, checks, dt
                 assert _tiny_cells(x) > 10000, "no tiny-value front at step %d" % st
             del x, y
     assert active >= len(checks) and off.get_counter("tb_plan_active") == 0
-    assert on.get_counter("halves_steps") + on.get_counter("tm_steps") >= steps - 20 and on.get_counter("halves_steps") >= 16 and on.get_counter("tm_steps") >= 16
-    assert on.get_counter("tm_choice") in (0, 1) and off.get_counter("halves_steps") + off.get_counter("tm_steps") == 0
+    assert on.get_counter("tm_choice") == 1 and on.get_param("gas_share") > 0.8, (on.get_counter("tm_choice"), on.get_param("gas_share"))
+    assert on.get_counter("tm_steps") >= steps - 20 and on.get_counter("pair_launches") >= steps - 20 and on.get_counter("halves_steps") == 0
+    assert off.get_counter("halves_steps") + off.get_counter("tm_steps") == 0
     F = on.get("F")
     assert F.min() >= 0.0 and F.max() <= 1.0 and on.get_counter("courant_violations") == 0
 
@@ -129,12 +130,13 @@ def test_strips_inside_the_front(hip_api, nstrips):
 
 
 def test_batch_forms_are_timed_again_and_switching_changes_no_value(hip_api):
-    """fuse_tm = -1 (the default) on a large fp64 grid: the handle alternates its two batch forms over four 8-step
+    """fuse_tm = -2 (exploration; the default, -1, chooses by a rule on the state) on a large fp64 grid: the handle alternates its two batch forms over four 8-step
     batches, keeps the faster, and does so again every `tune_period` batches.  With a period of 2 batches (of 16 steps) a run of 250
     steps goes through the timing three to four times: both forms run for dozens of steps each, in turns -- and the state
     equals the plain four-kernel sequence's value for value (4096^2 dam-break, the headline configuration)."""
     n = 4096
     a = engine(hip_api, n, n, "f64", "f32", ic=1)
+    a.set_param("fuse_tm", -2)
     a.set_param("tune_period", 2)
     b = engine(hip_api, n, n, "f64", "f32", ic=1)
     b.set_param("overlap_halves", 0)
@@ -149,3 +151,30 @@ def test_batch_forms_are_timed_again_and_switching_changes_no_value(hip_api):
     tm, ch = a.get_counter("tm_steps"), a.get_counter("halves_steps")
     assert tm >= 3 * 16 and ch >= 3 * 16 and tm + ch >= 230, (tm, ch)
     assert a.get_counter("tm_choice") in (0, 1) and b.get_counter("tm_steps") + b.get_counter("halves_steps") == 0
+
+
+def test_batch_form_follows_a_rule_on_the_state(hip_api):
+    """The default (fuse_tm = -1): which batch form a large fp64 full domain runs is a function of the state -- the share
+    of exact-zero cells of F when the handle first batches steps -- not of a stopwatch: two fresh handles agree, a
+    dam-break (5/6 gas) runs k_tm + k_jacobi_pair, a rising bubble (2 % gas) the chains, and where the rule does not
+    apply (fp32, small grids) the counter says so.  Replacing F makes the handle look again."""
+    n = 4096
+    a = engine(hip_api, n, n, "f64", "f32", ic=1)
+    b = engine(hip_api, n, n, "f64", "f32", ic=1)
+    for e in (a, b):
+        assert e.get_counter("tm_choice") == -1 and e.get_param("gas_share") == -1.0
+        e.step(40)
+    assert a.get_counter("tm_choice") == b.get_counter("tm_choice") == 1
+    assert a.get_param("gas_share") == b.get_param("gas_share") and 0.8 < a.get_param("gas_share") < 0.85
+    assert a.get_counter("tm_steps") == b.get_counter("tm_steps") >= 32 and a.get_counter("halves_steps") == 0
+    b.close()
+    a.set_init_F(2)                                   # the same handle, now a bubble: the rule looks at the new F
+    a.step(40)
+    assert a.get_counter("tm_choice") == 0 and a.get_param("gas_share") < 0.05
+    assert a.get_counter("halves_steps") >= 16
+    a.close()
+    c = engine(hip_api, n, n, "f32", "f32", ic=1)
+    d = engine(hip_api, 2048, 2048, "f64", "f32", ic=1)
+    for e in (c, d):
+        e.step(20)
+        assert e.get_counter("tm_choice") == -1 and e.get_counter("tm_steps") == 0

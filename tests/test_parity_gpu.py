@@ -852,7 +852,7 @@ def test_fused_transport_momentum_mid_size_twice(hip_api, dtype, ic, nx, ny):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,ic,n,ring,rows", [("f64", 1, 512, False, 0), ("f32", 2, 640, False, 0), ("f64", 3, 448, True, 0), ("f32", 1, 600, True, 48),
-                                                ("f64", 1, 300, True, 33)])
+                                                ("f64", 1, 300, True, 33), ("f64", 2, 384, False, 64), ("f64", 1, 512, True, 120), ("f32", 3, 512, False, 100)])
 def test_jacobi_pair_changes_no_value(hip_api, oracle_api, dtype, ic, n, ring, rows):
     """k_jacobi_pair (kernels/jacobi_pair.h): each two five-sweep launches of a step as ONE launch -- a workgroup is a pair
     of waves on one tile, the first wave's result rows and the rhs rows it loaded handed to the second through rings in

@@ -75,7 +75,7 @@ def main():
             from vof2d._lib import kernel_source_hash
             rec = {"nx": a.nx, "ny": a.ny, "dtype": a.dtype, "tag": a.tag, "hbm_bytes_per_launch": {}, "kernel_source_sha256": kernel_source_hash(),
                    "rule": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes", "kernels": {}}
-            for key, pat in (("tm", "k_tm<"), ("pair", "k_jacobi_pair<")):
+            for key, pat in (("tm", "k_tm<"), ("pair", "k_jacobi_pair<"), ("momentum", "k_momentum<"), ("transport", "k_transport<"), ("tb", "k_jacobi_tb<")):
                 vs = [(2 * v["fetch_kib"] + v["write_kib"]) * 1024 for k, v in agg.items() if pat in k and "fetch_kib" in v and "write_kib" in v]
                 if vs:
                     rec["hbm_bytes_per_launch"][key] = sum(vs) / len(vs)
@@ -94,6 +94,11 @@ def main():
                 key = "tb" if "k_jacobi_tb" in k else "single"
                 rec["hbm_bytes_per_launch"][key] = (2 * v["fetch_kib"] + v["write_kib"]) * 1024
                 rec["kernels"][key] = {"name": k, "fetch_size_kib": v["fetch_kib"], "write_size_kib": v["write_kib"]}
+        for key, pat in (("momentum", "k_momentum<"), ("transport", "k_transport<")):   # (the other kernels of the four-kernel step: bench.py's step traffic)
+            vs = [(2 * v["fetch_kib"] + v["write_kib"]) * 1024 for k, v in agg.items() if pat in k and "fetch_kib" in v and "write_kib" in v]
+            if vs:
+                rec["hbm_bytes_per_launch"][key] = sum(vs) / len(vs)
+                rec["kernels"][key] = [k for k in agg if pat in k]
         json.dump(rec, open(os.path.join(out, "jacobi_pmc.json"), "w"), indent=1)
 
 
