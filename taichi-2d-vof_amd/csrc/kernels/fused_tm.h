@@ -55,233 +55,241 @@ __device__ __forceinline__ void ring_get(Row<T, V>& w, const T (&row)[64 * V], i
   w.r = row[lane * V + V - (lane < 63 ? 0 : 1)];
 }
 
-template <typename T, int V, bool YFIRST, bool STORE_UV, bool BS, int ABL = 0>
-__global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __restrict__ F, T* __restrict__ Fn, int ntf,
-                                            const T* __restrict__ us, const T* __restrict__ vs, const T* __restrict__ p,
-                                            T* __restrict__ Uo, T* __restrict__ Vo, T* __restrict__ us_out,
-                                            T* __restrict__ vs_out, T* __restrict__ rhs,
-                                            unsigned long long* __restrict__ courant, int R, TbPlan tp, int first, int last) {
-  constexpr int W = 64 * V, HF = TmGeom::HF, STRIDE = W - 2 * HF;
-  static_assert(HF >= 4 + 3 && HF % V == 0, "momentum's inputs must lie inside the transport march's valid columns");
-  static_assert(sizeof(TbPlanShared) <= sizeof(TmRing<double, 2>) / 2, "the planner block borrows the ring's LDS");
-  __shared__ __attribute__((aligned(16))) char smem[sizeof(TmRing<T, V>) > sizeof(TbPlanShared) ? sizeof(TmRing<T, V>) : sizeof(TbPlanShared)];
-  const int plan_blocks = tp.masks != nullptr ? 1 : 0;
-  if (plan_blocks && blockIdx.x == 0) {   // the planner of the next step's k_jacobi_tb launches, as in k_momentum
-    tb_make_plan(g, tp, *reinterpret_cast<TbPlanShared*>(smem));
-    return;
-  }
-  TmRing<T, V>& ring = *reinterpret_cast<TmRing<T, V>*>(smem);
-  WaveTimer wt_(WT_TM);
-  const int pair = (int)blockIdx.x - plan_blocks;
-  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: transport, 1: momentum
-  const int lane = threadIdx.x & 63;
-  const int tj = pair % ntf, ch = pair / ntf;
-  const int c0 = 1 - HF + tj * STRIDE;
+// IN (interior pair, chosen per workgroup): every row the pair touches lies in [3, nx - 1] and every column of its tile in
+// [2, ny] -- no wall row, no ghost column, no clamp.  The marches are the same code with the wall tests folded to
+// constants: the row / column selects around every result (okN, okK, okP, urow, dom ...), the ghost mirrors, the
+// clamped 64-bit row addresses and most of the scalar bookkeeping go (a third of a wave's instructions, in a kernel whose
+// waves issue one instruction at a time and wait for each other at every row); 93 % of the pairs of a 4096^2 grid.
+
+// ------------------------------------------------------------------ transport march (k_transport's, rows tra .. trb)
+template <typename T, int V, bool YFIRST, bool STORE_UV, bool BS, bool IN, int ABL>
+__device__ __forceinline__ void tm_transport_march(const Geom& g, const Consts<T>& c, TmRing<T, V>& ring, const T* __restrict__ F,
+                                                   T* __restrict__ Fn, const T* __restrict__ us, const T* __restrict__ vs,
+                                                   const T* __restrict__ p, T* __restrict__ Uo, T* __restrict__ Vo,
+                                                   unsigned long long* __restrict__ courant, int c0, int lane, int ma, int mb,
+                                                   WaveTimer& wt_) {
+  constexpr int W = 64 * V, HF = TmGeom::HF;
+  // the transport wave is the one the momentum wave waits for: priority 1 (4096^2 fp64: 314 -> 299 us y first, 327 -> 305 x first;
+  // the momentum wave instead: 314 / 333).  ABL_PRIO0 of the diagnostic build = without it.
+  if constexpr ((ABL & ABL_PRIO0) == 0) __builtin_amdgcn_s_setprio(1);
   const int j0 = c0 + lane * V;
   const int ilo = g.ilo, ihi = g.ihi, nx = g.nx, ny = g.ny;
-  const int ma = first + ch * R;
-  if (ma > last) return;   // (block-uniform: both waves leave)
-  const int mb = ma + R - 1 < last ? ma + R - 1 : last;
-  const int jlo = c0 + HF > 1 ? c0 + HF : 1;
-  const int jhi = c0 + W - HF - 1 < ny ? c0 + W - HF - 1 : ny;
+  const int jlo = IN ? c0 + HF : (c0 + HF > 1 ? c0 + HF : 1);
+  const int jhi = IN ? c0 + W - HF - 1 : (c0 + W - HF - 1 < ny ? c0 + W - HF - 1 : ny);
   const int t_lo = ma - 5, t_hi = mb + 8;   // lockstep steps of the pair
+  const int64_t pitch = g.pitch;
   auto rowptr = [&](const T* base, int r) {
     if constexpr ((ABL & ABL_FIXED_ROW) != 0) r = ma;
-    const int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
+    const int rc = IN ? r : (r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r));
     return base + at(g, rc, j0);
   };
-
-  if (role == 0) {
-    // the transport wave is the one the momentum wave waits for: priority 1 (4096^2 fp64: 314 -> 299 us y first, 327 -> 305 x first;
-    // the momentum wave instead: 314 / 333).  ABL_PRIO0 of the diagnostic build = without it.
-    if constexpr ((ABL & ABL_PRIO0) == 0) __builtin_amdgcn_s_setprio(1);
-    // ------------------------------------------------------------------ transport march (k_transport's, rows tra .. trb)
-    const int tra = ma - 3, trb = mb + 3;
-    FctXPipe<T, V> pipe;
-    T p1[V], rho1[V];
-    {
-      T f1[V];
-      load_c<T, V>(f1, rowptr(F, tra - 3));
-      load_c<T, V>(p1, rowptr(p, tra - 3));
+  const int tra = ma - 3, trb = mb + 3;
+  FctXPipe<T, V> pipe;
+  T p1[V], rho1[V];
+  {
+    T f1[V];
+    load_c<T, V>(f1, rowptr(F, tra - 3));
+    load_c<T, V>(p1, rowptr(p, tra - 3));
 #pragma unroll
-      for (int q = 0; q < V; ++q) rho1[q] = rho_of(c, f1[q]);
-      if (YFIRST && tra - 3 >= ilo) {
-        T v0[V], fs[V];
-        load_s<T, V>(v0, rowptr(vs, tra - 3));
-        const T rhol = lane_up(rho1[V - 1]), pl = lane_up(p1[V - 1]);
+    for (int q = 0; q < V; ++q) rho1[q] = rho_of(c, f1[q]);
+    if (YFIRST && (IN || tra - 3 >= ilo)) {
+      T v0[V], fs[V];
+      load_s<T, V>(v0, rowptr(vs, tra - 3));
+      const T rhol = lane_up(rho1[V - 1]), pl = lane_up(p1[V - 1]);
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-          const int j = j0 + q;
-          const T vn = corrected_velocity<T>(c, v0[q], rho1[q], q == 0 ? rhol : rho1[q - 1], p1[q],
-                                             q == 0 ? pl : p1[q - 1], c.dyi);
-          v0[q] = (j >= 2 && j <= ny) ? vn : (T)0;
-        }
-        fct_y_row<T, V, false>(c, j0, ny, f1, v0, fs);
-        pipe.init(fs);
-      } else {
-        pipe.init(f1);
+      for (int q = 0; q < V; ++q) {
+        const int j = j0 + q;
+        const T vn = corrected_velocity<T>(c, v0[q], rho1[q], q == 0 ? rhol : rho1[q - 1], p1[q],
+                                           q == 0 ? pl : p1[q - 1], c.dyi);
+        v0[q] = (IN || (j >= 2 && j <= ny)) ? vn : (T)0;
       }
+      fct_y_row<T, V, false, IN>(c, j0, ny, f1, v0, fs);
+      pipe.init(fs);
+    } else {
+      pipe.init(f1);
     }
-    int cls1 = 2;
-    T v1[V], v2[V], v3[V];
+  }
+  int cls1 = 2;
+  T v1[V], v2[V], v3[V];
 #pragma unroll
-    for (int q = 0; q < V; ++q) v1[q] = v2[q] = v3[q] = (T)0;
-    T Fnx[V], usnx[V], vsnx[V], pnx[V];
-    load_c<T, V>(Fnx, rowptr(F, tra - 2));
-    load_s<T, V>(usnx, rowptr(us, tra - 2));
-    load_s<T, V>(vsnx, rowptr(vs, tra - 2));
-    load_c<T, V>(pnx, rowptr(p, tra - 2));
-    unsigned int viol = 0;
-    for (int t = t_lo; t <= t_hi; ++t) {
-      if (t <= trb + 3) {
-        const int r = t;
-        T Fr[V], ur[V], vr[V], pr[V];
+  for (int q = 0; q < V; ++q) v1[q] = v2[q] = v3[q] = (T)0;
+  T Fnx[V], usnx[V], vsnx[V], pnx[V];
+  load_c<T, V>(Fnx, rowptr(F, tra - 2));
+  load_s<T, V>(usnx, rowptr(us, tra - 2));
+  load_s<T, V>(vsnx, rowptr(vs, tra - 2));
+  load_c<T, V>(pnx, rowptr(p, tra - 2));
+  // BS: the one store of the march (F'') is a range-checked buffer store and the loads run one row past the march (a row
+  // that exists), so every memory instruction is unconditional and the wait for the rows requested a step ago is an
+  // exact count that leaves the store in flight
+  const T* const Fn_tile = Fn + (int64_t)(g.col0 + c0);
+  const int voff_st = (j0 >= jlo && j0 + V - 1 <= jhi) ? lane * (int)(V * sizeof(T)) : kBufSkip;
+  unsigned int viol = 0;
+  for (int t = t_lo; t <= t_hi; ++t) {
+    if (t <= trb + 3) {
+      const int r = t;
+      T Fr[V], ur[V], vr[V], pr[V];
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-          Fr[q] = Fnx[q]; ur[q] = usnx[q]; vr[q] = vsnx[q]; pr[q] = pnx[q];
-        }
-        if (r < trb + 3) {
-          load_c<T, V>(Fnx, rowptr(F, r + 1));
-          load_s<T, V>(usnx, rowptr(us, r + 1));
-          load_s<T, V>(vsnx, rowptr(vs, r + 1));
-          load_c<T, V>(pnx, rowptr(p, r + 1));
-        }
-        if constexpr ((ABL & ABL_PASS0) != 0) {   // timing only: the loaded rows go on as they are
+      for (int q = 0; q < V; ++q) {
+        Fr[q] = Fnx[q]; ur[q] = usnx[q]; vr[q] = vsnx[q]; pr[q] = pnx[q];
+      }
+      if (BS || r < trb + 3) {
+        load_c<T, V>(Fnx, rowptr(F, r + 1));
+        load_s<T, V>(usnx, rowptr(us, r + 1));
+        load_s<T, V>(vsnx, rowptr(vs, r + 1));
+        load_c<T, V>(pnx, rowptr(p, r + 1));
+      }
+      if constexpr ((ABL & ABL_PASS0) != 0) {   // timing only: the loaded rows go on as they are
 #pragma unroll
-          for (int q = 0; q < V; ++q) Fr[q] += pr[q] * (T)0;
-          ring_put<T, V>(ring.u[r & 7], lane, ur);
-          ring_put<T, V>(ring.v[r & 7], lane, vr);
-          ring_put<T, V>(ring.f[(r - 3) & 7], lane, Fr);
-          if (r - 3 >= ma && r - 3 <= mb && !(ABL & ABL_NO_STORE)) store_s<T, V>(Fn + at(g, r - 3, j0), Fr, j0, jlo, jhi);
-          wt_.barrier();
-          continue;
-        }
-        int cls = 2;
-        {
-          bool rz = true, ro = true;
+        for (int q = 0; q < V; ++q) Fr[q] += pr[q] * (T)0;
+        ring_put<T, V>(ring.u[r & 7], lane, ur);
+        ring_put<T, V>(ring.v[r & 7], lane, vr);
+        ring_put<T, V>(ring.f[(r - 3) & 7], lane, Fr);
+        if (r - 3 >= ma && r - 3 <= mb && !(ABL & ABL_NO_STORE)) store_s<T, V>(Fn + at(g, r - 3, j0), Fr, j0, jlo, jhi);
+        wt_.barrier();
+        continue;
+      }
+      int cls = 2;
+      {
+        bool rz = true, ro = true;
 #pragma unroll
-          for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
-          if (__all(rz)) {
-            cls = 0;
-          } else {
-#pragma unroll
-            for (int q = 0; q < V; ++q) ro = ro && Fr[q] == (T)1;
-            if (__all(ro)) cls = 1;
-          }
-        }
-        {  // update_uv for row r (:269-280)
-          const T pl = lane_up(pr[V - 1]);
-          const bool urow = r >= 2 && r <= nx;
-          const bool own = r >= ma && r <= mb;
-          if (cls != 2 && cls == cls1) {
-            const T k = cls ? c.dt_rho_l : c.dt_rho_g;
-#pragma unroll
-            for (int q = 0; q < V; ++q) {
-              const int j = j0 + q;
-              const T un = ur[q] - k * (pr[q] - p1[q]) * c.dxi;
-              ur[q] = urow ? un : (T)0;
-              const T vn = vr[q] - k * (pr[q] - (q == 0 ? pl : pr[q - 1])) * c.dyi;
-              vr[q] = (j >= 2 && j <= ny) ? vn : (T)0;
-              p1[q] = pr[q];
-            }
-          } else {
-            T rhor[V];
-            if (cls1 != 2) {
-#pragma unroll
-              for (int q = 0; q < V; ++q) rho1[q] = cls1 ? c.rho_l : c.rho_g;
-            }
-#pragma unroll
-            for (int q = 0; q < V; ++q) rhor[q] = rho_of(c, Fr[q]);
-            const T rhol = lane_up(rhor[V - 1]);
-#pragma unroll
-            for (int q = 0; q < V; ++q) {
-              const int j = j0 + q;
-              const T un = corrected_velocity<T>(c, ur[q], rhor[q], rho1[q], pr[q], p1[q], c.dxi);
-              ur[q] = urow ? un : (T)0;
-              const T vn = corrected_velocity<T>(c, vr[q], rhor[q], q == 0 ? rhol : rhor[q - 1], pr[q],
-                                                 q == 0 ? pl : pr[q - 1], c.dyi);
-              vr[q] = (j >= 2 && j <= ny) ? vn : (T)0;
-              p1[q] = pr[q];
-              rho1[q] = rhor[q];
-            }
-          }
-          if (own && r >= g.own_lo && r <= g.own_hi) {
-#pragma unroll
-            for (int q = 0; q < V; ++q) {
-              const int j = j0 + q;
-              if (j >= jlo && j <= jhi) {
-                if (urow && ur[q] * c.dt > c.cfl_x) viol++;
-                if (j >= 2 && vr[q] * c.dt > c.cfl_y) viol++;
-              }
-            }
-          }
-          ring_put<T, V>(ring.u[r & 7], lane, ur);
-          ring_put<T, V>(ring.v[r & 7], lane, vr);
-          if (STORE_UV && own && !(ABL & ABL_NO_STORE)) {
-            store_s<T, V>(Uo + at(g, r, j0), ur, j0, jlo, jhi);
-            store_s<T, V>(Vo + at(g, r, j0), vr, j0, jlo, jhi == ny ? ny + 1 : jhi);
-            if (r == nx) {
-              T zero[V];
-#pragma unroll
-              for (int q = 0; q < V; ++q) zero[q] = (T)0;
-              store_c<T, V>(Uo + at(g, r + 1, j0), zero, j0, jlo, jhi);
-            }
-          }
-          cls1 = cls;
-        }
-        T out[V];
-#pragma unroll
-        for (int q = 0; q < V; ++q) out[q] = (T)0;
-        const int io = r - 3;
-        if (YFIRST) {
-          T Fp[V];
-          if (r < ilo || r > ihi || cls == 0) {
-#pragma unroll
-            for (int q = 0; q < V; ++q) Fp[q] = Fr[q];
-          } else {
-            fct_y_row<T, V, false>(c, j0, ny, Fr, vr, Fp);
-          }
-          pipe.template push<true>(c, r, ilo, ihi, Fp, ur, out, cls == 0);
+        for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
+        if (__all(rz)) {
+          cls = 0;
         } else {
-          T Fp[V];
-          pipe.template push<false>(c, r, ilo, ihi, Fr, ur, Fp, cls == 0);   // F'[r-3]
-          if (io >= tra && io <= trb) {
-            bool rz = true;
 #pragma unroll
-            for (int q = 0; q < V; ++q) rz = rz && Fp[q] == (T)0;
-            if (!__all(rz)) fct_y_row<T, V, true>(c, j0, ny, Fp, v3, out);
-          }
+          for (int q = 0; q < V; ++q) ro = ro && Fr[q] == (T)1;
+          if (__all(ro)) cls = 1;
+        }
+      }
+      {  // update_uv for row r (:269-280)
+        const T pl = lane_up(pr[V - 1]);
+        const bool urow = IN || (r >= 2 && r <= nx);
+        const bool own = r >= ma && r <= mb;
+        if (cls != 2 && cls == cls1) {
+          const T k = cls ? c.dt_rho_l : c.dt_rho_g;
 #pragma unroll
           for (int q = 0; q < V; ++q) {
-            v3[q] = v2[q]; v2[q] = v1[q]; v1[q] = vr[q];
+            const int j = j0 + q;
+            const T un = ur[q] - k * (pr[q] - p1[q]) * c.dxi;
+            ur[q] = urow ? un : (T)0;
+            const T vn = vr[q] - k * (pr[q] - (q == 0 ? pl : pr[q - 1])) * c.dyi;
+            vr[q] = (IN || (j >= 2 && j <= ny)) ? vn : (T)0;
+            p1[q] = pr[q];
+          }
+        } else {
+          T rhor[V];
+          if (cls1 != 2) {
+#pragma unroll
+            for (int q = 0; q < V; ++q) rho1[q] = cls1 ? c.rho_l : c.rho_g;
+          }
+#pragma unroll
+          for (int q = 0; q < V; ++q) rhor[q] = rho_of(c, Fr[q]);
+          const T rhol = lane_up(rhor[V - 1]);
+#pragma unroll
+          for (int q = 0; q < V; ++q) {
+            const int j = j0 + q;
+            const T un = corrected_velocity<T>(c, ur[q], rhor[q], rho1[q], pr[q], p1[q], c.dxi);
+            ur[q] = urow ? un : (T)0;
+            const T vn = corrected_velocity<T>(c, vr[q], rhor[q], q == 0 ? rhol : rhor[q - 1], pr[q],
+                                               q == 0 ? pl : pr[q - 1], c.dyi);
+            vr[q] = (IN || (j >= 2 && j <= ny)) ? vn : (T)0;
+            p1[q] = pr[q];
+            rho1[q] = rhor[q];
           }
         }
-        ring_put<T, V>(ring.f[io & 7], lane, out);
-        if (io >= ma && io <= mb && !(ABL & ABL_NO_STORE)) store_s<T, V>(Fn + at(g, io, j0), out, j0, jlo, jhi);
-      }
-      wt_.barrier();
-    }
-    if (__any(viol != 0)) {
-      unsigned int tot = viol;
+        if (own && (IN || (r >= g.own_lo && r <= g.own_hi))) {
 #pragma unroll
-      for (int sft = 32; sft > 0; sft >>= 1) tot += __shfl_down(tot, sft, 64);
-      if (lane == 0) atomicAdd(courant, (unsigned long long)tot);
+          for (int q = 0; q < V; ++q) {
+            const int j = j0 + q;
+            if (j >= jlo && j <= jhi) {
+              if (urow && ur[q] * c.dt > c.cfl_x) viol++;
+              if ((IN || j >= 2) && vr[q] * c.dt > c.cfl_y) viol++;
+            }
+          }
+        }
+        ring_put<T, V>(ring.u[r & 7], lane, ur);
+        ring_put<T, V>(ring.v[r & 7], lane, vr);
+        if (STORE_UV && own && !(ABL & ABL_NO_STORE)) {
+          store_s<T, V>(Uo + at(g, r, j0), ur, j0, jlo, jhi);
+          store_s<T, V>(Vo + at(g, r, j0), vr, j0, jlo, jhi == ny ? ny + 1 : jhi);
+          if (r == nx) {
+            T zero[V];
+#pragma unroll
+            for (int q = 0; q < V; ++q) zero[q] = (T)0;
+            store_c<T, V>(Uo + at(g, r + 1, j0), zero, j0, jlo, jhi);
+          }
+        }
+        cls1 = cls;
+      }
+      T out[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) out[q] = (T)0;
+      const int io = r - 3;
+      if (YFIRST) {
+        T Fp[V];
+        if ((!IN && (r < ilo || r > ihi)) || cls == 0) {
+#pragma unroll
+          for (int q = 0; q < V; ++q) Fp[q] = Fr[q];
+        } else {
+          fct_y_row<T, V, false, IN>(c, j0, ny, Fr, vr, Fp);
+        }
+        pipe.template push<true, IN>(c, r, ilo, ihi, Fp, ur, out, cls == 0);
+      } else {
+        T Fp[V];
+        pipe.template push<false, IN>(c, r, ilo, ihi, Fr, ur, Fp, cls == 0);   // F'[r-3]
+        if (io >= tra && io <= trb) {
+          bool rz = true;
+#pragma unroll
+          for (int q = 0; q < V; ++q) rz = rz && Fp[q] == (T)0;
+          if (!__all(rz)) fct_y_row<T, V, true, IN>(c, j0, ny, Fp, v3, out);
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          v3[q] = v2[q]; v2[q] = v1[q]; v1[q] = vr[q];
+        }
+      }
+      ring_put<T, V>(ring.f[io & 7], lane, out);
+      const bool st = io >= ma && io <= mb;
+      if constexpr ((ABL & ABL_NO_STORE) != 0) {
+        asm volatile("" :: "v"(out[0]), "v"(out[V - 1]));
+      } else if constexpr (BS) {
+        store_buf_nt<T, V>(Fn_tile, st ? voff_st : kBufSkip, st ? (int)((int64_t)(io - g.row_lo) * pitch * (int64_t)sizeof(T)) : 0, out);
+      } else if (st) {
+        store_s<T, V>(Fn + at(g, io, j0), out, j0, jlo, jhi);
+      }
     }
-    return;
+    wt_.barrier();
   }
+  if (__any(viol != 0)) {
+    unsigned int tot = viol;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) tot += __shfl_down(tot, sft, 64);
+    if (lane == 0) atomicAdd(courant, (unsigned long long)tot);
+  }
+}
 
-  // -------------------------------------------------------------------- momentum march (k_momentum's, rows ma .. mb)
+// -------------------------------------------------------------------- momentum march (k_momentum's, rows ma .. mb)
+template <typename T, int V, bool BS, bool IN, int ABL>
+__device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>& c, TmRing<T, V>& ring, T* __restrict__ us_out,
+                                                  T* __restrict__ vs_out, T* __restrict__ rhs, int c0, int lane, int ma, int mb,
+                                                  WaveTimer& wt_) {
+  constexpr int W = 64 * V, HF = TmGeom::HF;
   if constexpr ((ABL & ABL_PRIO1) != 0) __builtin_amdgcn_s_setprio(1);
+  const int t_lo = ma - 5, t_hi = mb + 8;   // lockstep steps of the pair
   if constexpr ((ABL & ABL_IDLE1) != 0) {
     for (int t = t_lo; t <= t_hi; ++t) wt_.barrier();
     return;
   }
+  const int j0 = c0 + lane * V;
+  const int ilo = g.ilo, ihi = g.ihi, nx = g.nx, ny = g.ny;
+  const int jlo = IN ? c0 + HF : (c0 + HF > 1 ? c0 + HF : 1);
+  const int jhi = IN ? c0 + W - HF - 1 : (c0 + W - HF - 1 < ny ? c0 + W - HF - 1 : ny);
   const T dt = c.dt, dxi = c.dxi, dyi = c.dyi, dxi2 = c.dxi2, dyi2 = c.dyi2;
   bool dom[V];
 #pragma unroll
-  for (int q = 0; q < V; ++q) dom[q] = (j0 + q) >= 1 && (j0 + q) <= ny;
-  auto mirrow = [&](int r) { return r == 0 ? 1 : (r == nx + 1 ? nx : r); };   // virtual ghost rows of F and v (:176-189)
-  const bool edge_cols = (c0 - 1 <= 0 || c0 + W >= ny + 1);
+  for (int q = 0; q < V; ++q) dom[q] = IN || ((j0 + q) >= 1 && (j0 + q) <= ny);
+  auto mirrow = [&](int r) { return IN ? r : (r == 0 ? 1 : (r == nx + 1 ? nx : r)); };   // virtual ghost rows of F and v (:176-189)
+  const bool edge_cols = !IN && (c0 - 1 <= 0 || c0 + W >= ny + 1);
   auto get_F = [&](Row<T, V>& w, int r) { ring_get<T, V>(w, ring.f[mirrow(r) & 7], lane); };
   auto get_u = [&](Row<T, V>& w, int r) { ring_get<T, V>(w, ring.u[r & 7], lane); };
   auto get_v = [&](Row<T, V>& w, int r) { ring_get<T, V>(w, ring.v[mirrow(r) & 7], lane); };
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
         mirror_ghost_cols<T, V>(u1, j0, ny);
       }
       // ---- N: normals of row r-1 (:285-306)
-      const bool okN = (r - 1) >= ilo && (r - 1) <= ihi;
+      const bool okN = IN || ((r - 1) >= ilo && (r - 1) <= ihi);
       T mx1[V], my1[V];
       flat0 = row_flat<T, V>(F0);
       const bool flat = flat2 && flat1 && flat0 && F2.c[0] == F1.c[0] && F1.c[0] == F0.c[0];
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
         }
       }
       // ---- K: kappa of row r-2 (:307-309)
-      const bool okK = (r - 2) >= ilo && (r - 2) <= ihi;
+      const bool okK = IN || ((r - 2) >= ilo && (r - 2) <= ihi);
       const T myl = lane_up(my2[V - 1]), myr = lane_dn(my2[0]);
       T k2[V];
 #pragma unroll
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
       }
       // ---- P: u*, v* of row i = r-2 (:206-233)
       const int i = r - 2;
-      const bool okP = i >= ilo && i <= ihi;
+      const bool okP = IN || (i >= ilo && i <= ihi);
       const T kl = lane_up(k2[V - 1]);
       T us2[V], vs2[V], rho2[V];
 #pragma unroll
@@ -411,8 +419,8 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
                             u_here * dvdx - v00 * dvdy + c.gy + fyf[q]));
         }
         const int j = j0 + q;
-        us2[q] = (okP && i >= 2 && dom[q]) ? ou : (T)0;
-        vs2[q] = (okP && j >= 2 && j <= ny) ? ov : (T)0;
+        us2[q] = (okP && (IN || i >= 2) && dom[q]) ? ou : (T)0;
+        vs2[q] = (okP && (IN || (j >= 2 && j <= ny))) ? ov : (T)0;
       }
       if constexpr ((ABL & ABL_NO_STORE) != 0) {
         asm volatile("" :: "v"(us2[0]), "v"(us2[V - 1]), "v"(vs2[0]), "v"(vs2[V - 1]));
@@ -459,6 +467,42 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
       v3 = v2; v2 = v1;
     }
     wt_.barrier();
+  }
+}
+
+template <typename T, int V, bool YFIRST, bool STORE_UV, bool BS, int ABL = 0>
+__global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __restrict__ F, T* __restrict__ Fn, int ntf,
+                                            const T* __restrict__ us, const T* __restrict__ vs, const T* __restrict__ p,
+                                            T* __restrict__ Uo, T* __restrict__ Vo, T* __restrict__ us_out,
+                                            T* __restrict__ vs_out, T* __restrict__ rhs,
+                                            unsigned long long* __restrict__ courant, int R, TbPlan tp, int first, int last) {
+  constexpr int W = 64 * V, HF = TmGeom::HF, STRIDE = W - 2 * HF;
+  static_assert(HF >= 4 + 3 && HF % V == 0, "momentum's inputs must lie inside the transport march's valid columns");
+  static_assert(sizeof(TbPlanShared) <= sizeof(TmRing<double, 2>) / 2, "the planner block borrows the ring's LDS");
+  __shared__ __attribute__((aligned(16))) char smem[sizeof(TmRing<T, V>) > sizeof(TbPlanShared) ? sizeof(TmRing<T, V>) : sizeof(TbPlanShared)];
+  const int plan_blocks = tp.masks != nullptr ? 1 : 0;
+  if (plan_blocks && blockIdx.x == 0) {   // the planner of the next step's k_jacobi_tb launches, as in k_momentum
+    tb_make_plan(g, tp, *reinterpret_cast<TbPlanShared*>(smem));
+    return;
+  }
+  TmRing<T, V>& ring = *reinterpret_cast<TmRing<T, V>*>(smem);
+  WaveTimer wt_(WT_TM);
+  const int pair = (int)blockIdx.x - plan_blocks;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: transport, 1: momentum
+  const int lane = threadIdx.x & 63;
+  const int tj = pair % ntf, ch = pair / ntf;
+  const int c0 = 1 - HF + tj * STRIDE;
+  const int ma = first + ch * R;
+  if (ma > last) return;   // (block-uniform: both waves leave)
+  const int mb = ma + R - 1 < last ? ma + R - 1 : last;
+  // interior pair: rows ma - 6 .. mb + 6 in [3, nx - 1], columns c0 - 1 .. c0 + W in [1, ny + 1] with every lane's columns in [2, ny]
+  const bool interior = ma >= 9 && mb + 7 <= g.nx && c0 >= 2 && c0 + W - 1 <= g.ny && g.wall_lo && g.wall_hi;
+  if (role == 0) {
+    if (interior) tm_transport_march<T, V, YFIRST, STORE_UV, BS, true, ABL>(g, c, ring, F, Fn, us, vs, p, Uo, Vo, courant, c0, lane, ma, mb, wt_);
+    else tm_transport_march<T, V, YFIRST, STORE_UV, BS, false, ABL>(g, c, ring, F, Fn, us, vs, p, Uo, Vo, courant, c0, lane, ma, mb, wt_);
+  } else {
+    if (interior) tm_momentum_march<T, V, BS, true, ABL>(g, c, ring, us_out, vs_out, rhs, c0, lane, ma, mb, wt_);
+    else tm_momentum_march<T, V, BS, false, ABL>(g, c, ring, us_out, vs_out, rhs, c0, lane, ma, mb, wt_);
   }
 }
 

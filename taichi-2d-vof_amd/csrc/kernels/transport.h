@@ -82,7 +82,8 @@ __device__ __forceinline__ T corrected_velocity(const Consts<T>& c, T star, T rh
 
 // fct_y_sweep for one row segment: a wave's 64*V consecutive cells, valid for the inner columns
 // [c0+4, c0+W-5] (the j+-3 dependency is resolved across lanes; tiles overlap by 8 columns)
-template <typename T, int V, bool POST>
+// IN: every column the wave holds lies in [2, ny] (an interior tile of a pair kernel): the column tests are constants
+template <typename T, int V, bool POST, bool IN = false>
 __device__ __forceinline__ void fct_y_row(const Consts<T>& c, int j0, int ny, const T (&Fz)[V], const T (&vz)[V],
                                           T (&out)[V]) {
   const T Fl = lane_up(Fz[V - 1]);
@@ -95,7 +96,7 @@ __device__ __forceinline__ void fct_y_row(const Consts<T>& c, int j0, int ny, co
   for (int q = 0; q < V; ++q) {
     const int j = j0 + q;
     dv[q] = c.dxdy - c.dtdx * ((q == V - 1 ? vn : vz[q + 1]) - vz[q]);
-    td[q] = (j >= 1 && j <= ny) ? fct_ftd<T>(c, Fz[q], L[q], q == V - 1 ? Ln : L[q + 1], dv[q]) : (T)0;
+    td[q] = (IN || (j >= 1 && j <= ny)) ? fct_ftd<T>(c, Fz[q], L[q], q == V - 1 ? Ln : L[q + 1], dv[q]) : (T)0;
   }
   // Stages B, C, D.  Where every anti-diffusive flux the wave holds is an exact zero (F uniform along the sweep:
   // the bulk of either phase) the limiter ratios of :417-429 are 0 (pp = pm = 0), so are the face limiters, and stage
@@ -117,7 +118,7 @@ __device__ __forceinline__ void fct_y_row(const Consts<T>& c, int j0, int ny, co
   for (int q = 0; q < V; ++q) {
     const int j = j0 + q;
     rp[q] = rm[q] = (T)0;
-    if (j >= 1 && j <= ny)
+    if (IN || (j >= 1 && j <= ny))
       fct_ratios<T>(c, td[q], q == 0 ? tl : td[q - 1], q == V - 1 ? tr : td[q + 1], a[q],
                     q == V - 1 ? an_ : a[q + 1], rp[q], rm[q]);
   }
@@ -126,7 +127,7 @@ __device__ __forceinline__ void fct_y_row(const Consts<T>& c, int j0, int ny, co
 #pragma unroll
   for (int q = 0; q < V; ++q) {
     const int j = j0 + q;  // face j between cells j-1 and j; written for j in [2, ny+1]
-    cy[q] = (j >= 2 && j <= ny + 1)
+    cy[q] = (IN || (j >= 2 && j <= ny + 1))
                 ? fct_climit<T>(a[q], q == 0 ? rpl : rp[q - 1], q == 0 ? rml : rm[q - 1], rp[q], rm[q])
                 : (T)0;
   }
@@ -158,7 +159,8 @@ struct FctXPipe {
     nz1 = nz2 = nz3 = nzr3 = false;
   }
   // zero_row: Fr is an exact zero on every lane of the wave (the caller has looked at the row anyway)
-  template <bool POST>
+  // IN: rows r - 3 .. r all lie strictly inside [ilo, ihi] (an interior chunk of a pair kernel): the row tests are constants
+  template <bool POST, bool IN = false>
   __device__ __forceinline__ void push(const Consts<T>& c, int r, int ilo, int ihi, const T (&Fr)[V],
                                        const T (&ur)[V], T (&out)[V], bool zero_row) {
     zrows = zero_row ? zrows + 1 : 0;
@@ -178,7 +180,7 @@ struct FctXPipe {
       return;
     }
     const int i1 = r - 1, i2 = r - 2;
-    const bool in1 = i1 >= ilo && i1 <= ihi, in2 = i2 >= ilo && i2 <= ihi, inc2 = i2 > ilo && i2 <= ihi + 1;   // wave-uniform
+    const bool in1 = IN || (i1 >= ilo && i1 <= ihi), in2 = IN || (i2 >= ilo && i2 <= ihi), inc2 = IN || (i2 > ilo && i2 <= ihi + 1);   // wave-uniform
     T Lr[V], ar[V], dv1[V], tn[V];
     bool nzr = false;
 #pragma unroll
