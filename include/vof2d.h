@@ -50,7 +50,7 @@ extern "C" {
  * curvature 1 + predictor 1 + n Jacobi sweeps + update_uv 1 + fct_x_sweep 2
  * (velocity) = n + 5 on the low side, rhs 1 + n + fct_x_sweep 3 + ... = n + 5
  * on the high side; one spare row is allocated. */
-#define VOF_HALO_ROWS(jacobi_iters) ((jacobi_iters) + 6)
+#define VOF_HALO_ROWS(jacobi_iters) ((jacobi_iters) + 8)
 
 typedef struct vof2d_desc {
   int32_t abi_version;    /* VOF_ABI_VERSION */
@@ -234,10 +234,25 @@ int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep);
 #define VOF_XCHG_U 2u
 #define VOF_XCHG_V 4u
 #define VOF_XCHG_P 8u
+#define VOF_XCHG_US 16u   /* u*, v*, rhs: the exchange state of overlap mode 5 (next to F and p) */
+#define VOF_XCHG_VS 32u
+#define VOF_XCHG_RHS 64u
 int vof_comm_get_unique_id(void* id /* VOF_COMM_ID_BYTES */);
 int vof_comm_init(vof2d_handle h, const void* id, int32_t rank, int32_t world, int32_t flags);
 int vof_comm_exchange(vof2d_handle h, uint32_t field_mask);
 int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap);
+/* overlap = 5: the strips run the kernels the single GPU runs.  The step boundary moves behind the momentum predictor:
+ *   one call of n steps = k_momentum (owned rows), send/recv u*, v*, rhs
+ *                         + (n - 1) x [k_jacobi_pair (ten sweeps, all stored rows), k_tm (this step's transport + the next
+ *                           step's momentum) on the two edge bands beside k_tm on the other owned rows, send/recv F, u*, v*,
+ *                           rhs, p in one group under the latter]
+ *                         + [two k_jacobi_tb launches, k_transport on the edge bands, send/recv F, u, v, p, k_transport on
+ *                           the other rows]  (the last step is mode 4's: u and v reach memory only there),
+ * the middle steps two per hipGraph launch.  Halo depth: ten sweeps + 7 rows of the fused transport / momentum
+ * marches <= VOF_HALO_ROWS.  vof_step_tm_piece runs the kernels of one piece WITHOUT the exchange (0: the k_momentum of
+ * the first step, 1: one middle step, 2: the last step), for drivers that move the halos themselves (vof_copy_rows between
+ * strip handles on one device: tests, tools/predict_strips.py). */
+int vof_step_tm_piece(vof2d_handle h, int32_t piece);
 /* max over all ranks of *value (ncclAllReduce on the compute stream, then a stream sync): the
  * global residual of the residual-terminated pressure solve, and a barrier for timing loops. */
 int vof_comm_allreduce_max(vof2d_handle h, double* value);

@@ -157,6 +157,8 @@ struct vof2d_ctx {
   int buf_stores = 7;      // range-checked buffer stores where the grid allows (buffer_stores_ok): bit 0 k_momentum, bit 1 k_jacobi_tb, bit 2 k_tm's momentum wave
   int virtual_ghosts = 1;  // ... without the step's set_BC launch (k_momentum forms the ghost cells it reads)
   void* f_home = nullptr;  // the buffer fld[fF] pointed to at creation (orientation of the F / twin pair)
+  void* us_home = nullptr; // ... fld[fUS] (the u*, v* pair alternates with mx, my in the k_tm forms) and fld[fP] (k_jacobi_pair alternates p / pt)
+  void* p_home = nullptr;
   int phase_graph_ori = 0; // orientation the gphase / gxchg graphs were captured in
   hipGraphExec_t gexec[2][2] = {};  // whole step, [istep parity][F in its home buffer ? 0 : 1]
   // several consecutive steady-state steps of a full domain as ONE graph (step_batch[b] steps, an even number: the

@@ -386,19 +386,26 @@ struct L {
   // k_transport of this step + k_momentum of the next in one launch (k_tm): reads fld[fF], fld[fUS], fld[fVS], fld[fP];
   // writes fld[fF2], rhs, u*' / v*' into fld[fMX] / fld[fMY] (the caller alternates the pairs and swaps F), u and v
   // only with STORE_UV; adapt_par: parity of the NEXT step (its planner block rides here as it does in k_momentum)
+  static int tm_chunk_rows(const vof2d_ctx* h, long rows, int ntf, long cap) {
+    if (h->tm_rows > 0) return h->tm_rows;
+    long k = (rows * ntf + cap * 25) / (cap * 50);
+    if (k < 2) k = 2;
+    long chunks = k * cap * 97 / 100 / ntf;
+    if (chunks < 1) chunks = 1;
+    const long R = (rows + chunks - 1) / chunks;
+    return (int)(R < 16 ? 16 : (R > 96 ? 96 : R));
+  }
   template <bool YFIRST, bool STORE_UV>
-  static void tm(vof2d_ctx* h, int adapt_par, int first = 1, int last = 0) {
+  static void tm(vof2d_ctx* h, int adapt_par, int first = 1, int last = 0, int rows_forced = 0) {
     if (last < first) { first = h->g.ilo; last = h->g.ihi; }
     constexpr int ST = 64 * V - 2 * TmGeom::HF;
     const int ntf = (h->g.ny + ST - 1) / ST;
-    // pair chunks: about two and a half residency rounds (6 pairs per CU: 24 KB of LDS each) -- 4096^2, 112-column tiles:
-    // 24 rows 0.5115 ms/step, 32 0.4938, 40 0.4847, 44 0.4868, 48 0.4892, 56 0.4912, 64 0.4873, 72 0.5213 (1.4 rounds);
-    // 3072^2: 24 0.332, 32 0.329, 40 0.338; 8192^2: 80 1.575, 104 1.582, 128 1.617, 160 1.607
-    int R = h->tm_rows;
-    if (R <= 0) {
-      R = (int)(((long)(h->g.ihi - h->g.ilo + 1) * ntf / 3800 + 4) / 8 * 8);
-      R = R < 16 ? 16 : (R > 96 ? 96 : R);
-    }
+    // pair chunks: a whole number of residency rounds, just filled (6 pairs per CU: 24 KB of LDS each) -- a launch that needs a
+    // little more than k rounds pays for k + 1 --, as many rounds as keep the chunks near 50 rows (one round of 100-row
+    // chunks: every step of every pair takes 3.3 us instead of 1.9).  4096^2, 112-column tiles, us per launch: 40 rows
+    // (2.5 rounds) 261 / 281 (inside / behind the front), 48 252 / 282, 52 253 / 280, 54 256 / 277, 56 257 / 284,
+    // 100 376 / 381 (tools/probes/pair_bound.py --rows)
+    const int R = rows_forced > 0 ? rows_forced : tm_chunk_rows(h, last - first + 1, ntf, resident_blocks(h, k_tm<T, V, YFIRST, STORE_UV, true>, 128));
     const TbPlan tp = tb_plan(h, adapt_par);
     const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf) + (tp.masks ? 1u : 0u);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 4);

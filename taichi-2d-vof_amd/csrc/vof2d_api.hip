@@ -97,6 +97,8 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
     for (int k = 0; k < NFIELDS; ++k) h->fld[k] = h->arena + (size_t)k * h->field_elems * h->esz;
 #endif
     h->f_home = h->fld[fF];
+    h->us_home = h->fld[fUS];
+    h->p_home = h->fld[fP];
     if (hipMalloc(reinterpret_cast<void**>(&h->d_courant), 4 * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
     if (hipMemsetAsync(h->d_courant, 0, 4 * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipMalloc(reinterpret_cast<void**>(&h->d_tbmask), (2 * TB_BANDS * (TB_COLS / 64) + 1 + kTbPlanWaves) * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }

@@ -13,6 +13,7 @@ VOF_OK, VOF_EINVAL, VOF_EHIP, VOF_ENOMEM, VOF_ESTATE = 0, -1, -2, -3, -4
 VOF_FLAG_NO_GRAPH = 1
 VOF_COMM_ID_BYTES, VOF_COMM_LOOPBACK = 128, 1
 VOF_XCHG_F, VOF_XCHG_U, VOF_XCHG_V, VOF_XCHG_P = 1, 2, 4, 8
+VOF_XCHG_US, VOF_XCHG_VS, VOF_XCHG_RHS = 16, 32, 64
 VOF_RESID_ABS, VOF_RESID_REL, VOF_RESID_TINY = 0, 1, 1e-300
 
 ERRNAMES = {VOF_EINVAL: "VOF_EINVAL", VOF_EHIP: "VOF_EHIP", VOF_ENOMEM: "VOF_ENOMEM",
@@ -21,7 +22,7 @@ ERRNAMES = {VOF_EINVAL: "VOF_EINVAL", VOF_EHIP: "VOF_EHIP", VOF_ENOMEM: "VOF_ENO
 
 def halo_rows(jacobi_iters):
     """VOF_HALO_ROWS of include/vof2d.h."""
-    return int(jacobi_iters) + 6
+    return int(jacobi_iters) + 8
 
 
 class Desc(C.Structure):
@@ -96,6 +97,7 @@ SIGNATURES = {
     "comm_init": (C.c_int, [H, C.c_void_p, _i32, _i32, _i32]),
     "comm_exchange": (C.c_int, [H, C.c_uint32]),
     "step_exchange": (C.c_int, [H, _i64, _i32]),
+    "step_tm_piece": (C.c_int, [H, _i32]),
     "comm_allreduce_max": (C.c_int, [H, C.POINTER(_dbl)]),
     "comm_info": (C.c_int, [H, C.POINTER(_i32), C.POINTER(_i32)]),
     "comm_destroy": (C.c_int, [H]),
@@ -107,7 +109,7 @@ SIGNATURES = {
 
 # entry points that only the GPU library implements (timing / profiling on a HIP stream)
 GPU_ONLY = ("timer_start", "timer_stop", "time_jacobi", "profile_steps", "get_profile", "reset_profile",
-            "selftest_division", "comm_get_unique_id", "comm_init", "comm_exchange", "step_exchange", "comm_destroy",
+            "selftest_division", "comm_get_unique_id", "comm_init", "comm_exchange", "step_exchange", "step_tm_piece", "comm_destroy",
             "comm_allreduce_max", "comm_info")
 
 

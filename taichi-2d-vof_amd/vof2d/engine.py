@@ -239,8 +239,14 @@ class Engine:
     def step_exchange(self, nsteps=1, overlap=1):
         """overlap: 0 = one exchange after the step, 1 = per field as soon as final, 3 = p, u, v in one
         group after the first sweep, 4 = fused transport on the edge bands first, one group for all
-        four fields under the transport of the other rows (the drivers' default)."""
+        four fields under the transport of the other rows, 5 = the pair kernels of the single GPU (k_jacobi_pair, k_tm)
+        with u*, v*, rhs, F, p exchanged once per step (include/vof2d.h)."""
         self._ck(self.api.step_exchange(self._h, int(nsteps), int(overlap)), "step_exchange")
+
+    def step_tm_piece(self, piece):
+        """The kernels of one piece of an overlap-mode-5 call without the exchange: 0 = the first step's k_momentum,
+        1 = one middle step (k_jacobi_pair, k_tm), 2 = the last step (k_jacobi_tb x 2, k_transport)."""
+        self._ck(self.api.step_tm_piece(self._h, int(piece)), "step_tm_piece")
 
     def comm_allreduce_max(self, value):
         v = C.c_double(float(value))

@@ -27,6 +27,9 @@ ap.add_argument("-ic", type=int, default=1)
 ap.add_argument("--dt", type=float, default=0.0)
 ap.add_argument("--rows", action="store_true")
 ap.add_argument("--map", action="store_true")
+ap.add_argument("--tm-rows", default="24,32,40,48,56,64,80,96,128")
+ap.add_argument("--pair-rows", default="40,56,64,72,80,96,120,160")
+ap.add_argument("--no-ablations", action="store_true")
 a = ap.parse_args()
 from vof2d import _abi
 from vof2d.engine import Engine, make_desc
@@ -104,7 +107,7 @@ for at in [int(x) for x in a.at.split(",")]:
     done = at
     e.sync()
     print("== %d^2 fp64 ic %d after %d steps (tm_steps %d, pair_launches %d)" % (a.n, a.ic, at, e.get_counter("tm_steps"), e.get_counter("pair_launches")), flush=True)
-    for which, plan, label in KERNELS:
+    for which, plan, label in (() if a.no_ablations else KERNELS):
         base = []
         line = []
         for rnd in range(2):
@@ -120,7 +123,7 @@ for at in [int(x) for x in a.at.split(",")]:
             print(" wave map of one launch of %s:" % label)
             wave_map(which, kid, plan, stride, None)
     if a.rows:
-        for knob, which, vals in (("tm_rows", 1, (24, 32, 40, 48, 56, 64, 80, 96, 128)), ("jacobi_pair_rows", 0, (40, 56, 64, 72, 80, 96, 120, 160))):
+        for knob, which, vals in (("tm_rows", 1, tuple(int(x) for x in a.tm_rows.split(","))), ("jacobi_pair_rows", 0, tuple(int(x) for x in a.pair_rows.split(",")))):
             res = []
             for v in vals + (0,):
                 e.set_param(knob, v)
