@@ -21,7 +21,7 @@
 //     step <= r' + 4, and u / v row r' - 1.  One barrier per step; ring slot = row & 7;
 //   * u*', v*' go to a second pair of arrays (chunks of other workgroups still read the old u*, v*); the caller
 //     alternates the pairs.
-// Full domains, virtual ghosts (the steady-state fused step) only.
+// Virtual ghosts (the steady-state fused step) only; on a strip the rows beyond its stored rows are the clamped edge rows (the invalid fringe).
 // The two marches below are k_transport's and k_momentum's row loops with the source / sink of F'', u, v exchanged (LDS
 // instead of memory) and the chunk bounds of the pair; they are kept as copies, not shared with the stand-alone kernels,
 // so that those kernels' register allocation and instruction schedule stay what profiles/ measured.
@@ -496,7 +496,8 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
   if (ma > last) return;   // (block-uniform: both waves leave)
   const int mb = ma + R - 1 < last ? ma + R - 1 : last;
   // interior pair: rows ma - 6 .. mb + 6 in [3, nx - 1], columns c0 - 1 .. c0 + W in [1, ny + 1] with every lane's columns in [2, ny]
-  const bool interior = ma >= 9 && mb + 7 <= g.nx && c0 >= 2 && c0 + W - 1 <= g.ny && g.wall_lo && g.wall_hi;
+  // (on a strip also inside the stored rows: the interior marches do not clamp their row addresses)
+  const bool interior = ma >= 9 && mb + 7 <= g.nx && ma - 6 >= g.row_lo && mb + 7 <= g.row_hi && c0 >= 2 && c0 + W - 1 <= g.ny;
   if (role == 0) {
     if (interior) tm_transport_march<T, V, YFIRST, STORE_UV, BS, true, ABL>(g, c, ring, F, Fn, us, vs, p, Uo, Vo, courant, c0, lane, ma, mb, wt_);
     else tm_transport_march<T, V, YFIRST, STORE_UV, BS, false, ABL>(g, c, ring, F, Fn, us, vs, p, Uo, Vo, courant, c0, lane, ma, mb, wt_);

@@ -94,25 +94,32 @@ void destroy_xchg_graphs(vof2d_ctx* h) {
   for (int a = 0; a < 2; ++a)
     for (int o = 0; o < 2; ++o)
       if (h->gxchg2[a][o]) { (void)hipGraphExecDestroy(h->gxchg2[a][o]); h->gxchg2[a][o] = nullptr; }
+  for (int k = 0; k < 16; ++k)
+    if (h->gxchg5[k]) { (void)hipGraphExecDestroy(h->gxchg5[k]); h->gxchg5[k] = nullptr; }
 }
-int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1) {
+// (s_in_alt: between the launches of k_tm and the host's swap the new u*, v* still live in the mx / my arrays;
+// on_cstream: whatever the messages wait for was enqueued on the communication stream itself)
+int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1, bool s_in_alt = false, bool on_cstream = false) {
   Rccl* r = rccl();
   const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
   const size_t row_bytes = (size_t)h->g.pitch * h->esz, bytes = (size_t)W * row_bytes;
-  hipEvent_t ready = fork >= 0 ? h->ev_fork[fork] : h->ev_ready;
-  HIPCHK(h, hipEventRecord(ready, h->stream));
-  HIPCHK(h, hipStreamWaitEvent(h->cstream, ready, 0));
-  static const int ids[4] = {fF, fU, fV, fP};
+  if (!on_cstream) {
+    hipEvent_t ready = fork >= 0 ? h->ev_fork[fork] : h->ev_ready;
+    HIPCHK(h, hipEventRecord(ready, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->cstream, ready, 0));
+  }
+  static const int ids[7] = {fF, fU, fV, fP, fUS, fVS, fRHS};
   NCCLCHK(h, r->GroupStart());
   // Inside the group no early return: a failing send / recv must still be followed by GroupEnd, or
   // the next (eager) exchange would nest inside the group left open and never be issued.
   int first_err = 0;
   const char* what = "";
   auto note = [&](int rc, const char* call) { if (rc != 0 && first_err == 0) { first_err = rc; what = call; } };
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 7; ++k) {
     if (!(mask & (1u << k))) continue;
     // between the two transport phases the new F still lives in the twin buffer
-    char* base = reinterpret_cast<char*>(h->fld[(k == 0 && f_in_twin) ? fF2 : ids[k]]);
+    const int id = (k == 0 && f_in_twin) ? fF2 : (k == 4 && s_in_alt) ? fMX : (k == 5 && s_in_alt) ? fMY : ids[k];
+    char* base = reinterpret_cast<char*>(h->fld[id]);
     auto row = [&](int g) { return base + (size_t)(g - h->d.row_lo) * row_bytes; };
     if (h->peer_lo >= 0) {
       note(r->Send(row(h->d.own_lo), bytes, /*ncclInt8*/ 0, h->peer_lo, h->comm, h->cstream), "ncclSend(lo)");
@@ -176,6 +183,96 @@ int enqueue_step_exchange(vof2d_ctx* h, int mode) {
   if ((rc = comm_post(h, mode ? VOF_XCHG_F : (VOF_XCHG_F | VOF_XCHG_U | VOF_XCHG_V | VOF_XCHG_P), false, 2))) return rc;
   if ((rc = comm_join(h))) return rc;           // halos complete before the next step
   if (lean && !virt) L<T>::template set_bc<BC_ALL>(h);
+  return VOF_OK;
+}
+
+// ---- overlap mode 5: the strips run the pair kernels (include/vof2d.h, vof_step_exchange) ----
+// owned rows of the handle inside the computable rows, and the two W-row bands at its interior edges
+struct OwnedRows { int lo, hi, in_lo, in_hi; bool band_lo, band_hi; };
+inline OwnedRows owned_rows(const vof2d_ctx* h) {
+  const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
+  OwnedRows o;
+  o.lo = h->d.own_lo > h->g.ilo ? h->d.own_lo : h->g.ilo;
+  o.hi = h->d.own_hi < h->g.ihi ? h->d.own_hi : h->g.ihi;
+  o.band_lo = !h->g.wall_lo; o.band_hi = !h->g.wall_hi;
+  o.in_lo = o.band_lo ? o.lo + W : o.lo;
+  o.in_hi = o.band_hi ? o.hi - W : o.hi;
+  return o;
+}
+// the first step's k_momentum: u*, v*, rhs of the owned rows (their halo rows arrive by exchange: mode 5's state)
+template <typename T>
+void tm5_head(vof2d_ctx* h) {
+  const OwnedRows o = owned_rows(h);
+  h->jpair_active = L<T>::jacobi_pair_ok(h);    // (the planner block plans the geometry of the kernel that will run)
+  L<T>::momentum(h, true, (int)((h->istep + 1) & 1), o.lo, o.hi);
+  h->jpair_active = false;
+}
+// the ten sweeps of a middle step on all stored rows
+template <typename T>
+void tm5_jacobi(vof2d_ctx* h, int par) {
+  if (L<T>::jacobi_pair_ok(h)) {
+    h->jpair_active = true;
+    L<T>::jacobi_pair(h, fP, fPT, par);
+    h->jpair_active = false;
+    swap_P(h);
+  } else {
+    jacobi_n<T>(h, h->d.jacobi_iters, false, -1);
+  }
+}
+// k_tm on the owned rows: part 0 = all, 1 = the edge bands (short chunks), 2 = the rest (carries the planner block)
+template <typename T>
+void tm5_tm(vof2d_ctx* h, int64_t istep, int part) {
+  const OwnedRows o = owned_rows(h);
+  const bool y_first = (istep % 2 == 0);
+  const int par_next = (int)((istep + 1) & 1);
+  h->jpair_active = L<T>::jacobi_pair_ok(h);
+  auto run = [&](int a, int b, int par, int rows_forced) {
+    if (b < a) return;
+    if (y_first) L<T>::template tm<true, false>(h, par, a, b, rows_forced); else L<T>::template tm<false, false>(h, par, a, b, rows_forced);
+  };
+  const bool split = o.in_lo <= o.in_hi && (o.band_lo || o.band_hi);
+  if (part == 0 || !split) {
+    if (part == 0 || (part == 1 && (o.band_lo || o.band_hi)) || (part == 2 && !(o.band_lo || o.band_hi))) run(o.lo, o.hi, par_next, 0);   // (one launch for the step: it carries the planner block)
+  } else if (part == 1) {
+    const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
+    if (o.band_lo) run(o.lo, o.in_lo - 1, -1, W);
+    if (o.band_hi) run(o.in_hi + 1, o.hi, -1, W);
+  } else {
+    run(o.in_lo, o.in_hi, par_next, 0);
+  }
+  h->jpair_active = false;
+}
+// one middle step with its exchange: the edge bands on the communication stream in front of the send / recv group,
+// the other rows on the compute stream beside them (launches of k_tm on disjoint rows read the old arrays and write
+// the new ones: they do not depend on each other)
+template <typename T>
+int enqueue_mid_step5(vof2d_ctx* h) {
+  int rc;
+  tm5_jacobi<T>(h, (int)(h->istep & 1));
+  HIPCHK(h, hipEventRecord(h->ev_fork[1], h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->cstream, h->ev_fork[1], 0));
+  hipStream_t st = h->stream;
+  h->stream = h->cstream;
+  tm5_tm<T>(h, h->istep, 1);
+  h->stream = st;
+  if ((rc = comm_post(h, VOF_XCHG_F | VOF_XCHG_US | VOF_XCHG_VS | VOF_XCHG_RHS | VOF_XCHG_P, /*f_in_twin=*/true, 1, /*s_in_alt=*/true, /*on_cstream=*/true))) return rc;
+  tm5_tm<T>(h, h->istep, 2);
+  swap_F(h);
+  swap_S(h);
+  return comm_join(h);
+}
+// the last step of a call: mode 4's step without its k_momentum (u, v reach memory here)
+template <typename T>
+int enqueue_tail_step5(vof2d_ctx* h) {
+  int rc;
+  jacobi_n<T>(h, h->d.jacobi_iters, false, -1);     // (uniform chunks: the plan in memory is of the pairs' geometry)
+  const bool y_first = (h->istep % 2 == 0);
+  transport_part<T>(h, y_first, kEdgeBands);
+  if ((rc = comm_post(h, VOF_XCHG_P | VOF_XCHG_F | VOF_XCHG_U | VOF_XCHG_V, /*f_in_twin=*/true, 1))) return rc;
+  transport_part<T>(h, y_first, kRest);
+  swap_F(h);
+  if ((rc = comm_join(h))) return rc;
+  if (!h->virtual_ghosts) L<T>::template set_bc<BC_ALL>(h);
   return VOF_OK;
 }
 

@@ -224,6 +224,8 @@ struct vof2d_ctx {
   hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr};  // one per exchange of a step (graph capture forks)
   hipGraphExec_t gxchg[2][5][2] = {};   // whole step + exchanges, [istep parity][overlap mode][F / twin orientation]
   hipGraphExec_t gxchg2[2][2] = {};     // TWO mode-4 steps + exchanges per launch, [parity of the first][orientation] (vof_step_exchange)
+  hipGraphExec_t gxchg5[16] = {};       // TWO middle steps of mode 5 per launch, [parity | F orientation << 1 | u*, v* orientation << 2 | p orientation << 3]
+  int xchg5_graph = 1;                  // ... while this RCCL / runtime captures them
   int xchg_pair = 1;                 // 0 after a failed capture of a pair: one step per launch
   int xchg_graph = 1;                // 0 after a failed capture (or VOF2D_XCHG_GRAPH=0): eager launches
   int64_t xchg_steps = 0;            // steps run by vof_step_exchange (the first one is always eager)

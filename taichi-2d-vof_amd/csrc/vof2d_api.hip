@@ -999,22 +999,133 @@ int vof_comm_destroy(vof2d_handle h) {
   comm_teardown(h);
   return VOF_OK;
 }
-static unsigned field_mask_ok(uint32_t mask) { return mask != 0 && (mask & ~15u) == 0; }
+static unsigned field_mask_ok(uint32_t mask) { return mask != 0 && (mask & ~127u) == 0; }
 int vof_comm_exchange(vof2d_handle h, uint32_t field_mask) {
   if (!h) return VOF_EINVAL;
   if (!h->comm) return fail(h, VOF_ESTATE, "vof_comm_init has not been called");
-  if (!field_mask_ok(field_mask)) return fail(h, VOF_EINVAL, "field_mask: VOF_XCHG_F | _U | _V | _P");
+  if (!field_mask_ok(field_mask)) return fail(h, VOF_EINVAL, "field_mask: VOF_XCHG_F | _U | _V | _P | _US | _VS | _RHS");
   HIPCHK(h, hipSetDevice(h->device));
   settle_ghosts(h);
   int rc = comm_post(h, field_mask);
   return rc ? rc : comm_join(h);
 }
 
+// the kernels of mode 5 need: two-column tiles whose lanes are stored or skipped together, square cells or not (k_jacobi_pair
+// falls back to two k_jacobi_tb launches), the fused transport and its virtual ghosts
+static bool mode5_ok(const vof2d_ctx* h) {
+  return h->fuse_transport && h->tb >= 5 && h->d.jacobi_iters % 5 == 0 && h->d.jacobi_iters >= 5 && h->g.nx >= 16;
+}
+int vof_step_tm_piece(vof2d_handle h, int32_t piece) {
+  if (!h || piece < 0 || piece > 2) return VOF_EINVAL;
+  if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
+  if (!mode5_ok(h)) return fail(h, VOF_ESTATE, "the pair kernels need the fused transport and five-sweep Jacobi launches");
+  if (h->f_ghosts_dirty || h->uv_ghosts_dirty) return fail(h, VOF_ESTATE, "the first step after set_init_F / set_field runs through vof_step");
+  if (piece == 0) {
+    DISPATCH_T(h, tm5_head<double>(h), tm5_head<float>(h));
+  } else if (piece == 1) {
+    h->istep += 1;
+    DISPATCH_T(h, (tm5_jacobi<double>(h, (int)(h->istep & 1)), tm5_tm<double>(h, h->istep, 0)), (tm5_jacobi<float>(h, (int)(h->istep & 1)), tm5_tm<float>(h, h->istep, 0)));
+    swap_F(h);
+    swap_S(h);
+  } else {
+    h->istep += 1;
+    const bool y_first = (h->istep % 2 == 0);
+    DISPATCH_T(h, (jacobi_n<double>(h, h->d.jacobi_iters, false, -1), transport_part<double>(h, y_first, kAllOwned)),
+               (jacobi_n<float>(h, h->d.jacobi_iters, false, -1), transport_part<float>(h, y_first, kAllOwned)));
+    swap_F(h);
+    if (!h->virtual_ghosts) DISPATCH_T(h, L<double>::set_bc<BC_ALL>(h), L<float>::set_bc<BC_ALL>(h));
+  }
+  h->ghosts_virtual = h->virtual_ghosts != 0;
+  return ensure_ok(h);
+}
+// n steps of mode 5: see include/vof2d.h.  The middle steps are replayed two per hipGraph launch (all three pairs of
+// arrays -- F / twin, u* v* / mx my, p / pt -- are back where they were after two steps); the head and the tail of a
+// call, and an odd middle step, are launched eagerly.
+static int step_exchange_mode5(vof2d_handle h, int64_t nsteps) {
+  int rc;
+  if (!mode5_ok(h)) return fail(h, VOF_ESTATE, "overlap mode 5 needs the fused transport and five-sweep Jacobi launches");
+  if (nsteps == 0) return VOF_OK;
+  if (h->f_ghosts_dirty || h->uv_ghosts_dirty || h->xchg_steps == 0) {
+    // the first step after set_init_F / set_field (the reference's intermediate set_BC calls), and the first of a
+    // communicator (RCCL connects on first use): a step of mode 1
+    if ((rc = vof_step_exchange(h, 1, 1))) return rc;
+    if (--nsteps == 0) return VOF_OK;
+  }
+  const bool want_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH) && h->xchg_graph && h->xchg5_graph;
+  // head
+  DISPATCH_T(h, tm5_head<double>(h), tm5_head<float>(h));
+  if ((rc = comm_post(h, VOF_XCHG_US | VOF_XCHG_VS | VOF_XCHG_RHS))) return rc;
+  if ((rc = comm_join(h))) return rc;
+  int64_t mid = nsteps - 1;
+  auto eager_mid = [&]() -> int {
+    h->istep += 1;
+    int r2 = VOF_OK;
+    DISPATCH_T(h, r2 = enqueue_mid_step5<double>(h), r2 = enqueue_mid_step5<float>(h));
+    h->xchg_steps += 1;
+    return r2;
+  };
+  if (mid & 1) { if ((rc = eager_mid())) return rc; mid -= 1; }
+  while (mid > 0) {
+    const int key = (int)((h->istep + 1) & 1) | ((h->fld[fF] == h->f_home ? 0 : 1) << 1) | ((h->fld[fUS] == h->us_home ? 0 : 1) << 2) | ((h->fld[fP] == h->p_home ? 0 : 1) << 3);
+    if (want_graph && h->xchg5_graph && !h->gxchg5[key]) {
+      void* keep[NFIELDS];
+      memcpy(keep, h->fld, sizeof(keep));
+      const int64_t istep0 = h->istep;
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed);
+      rc = VOF_OK;
+      if (e == hipSuccess) {
+        for (int k = 0; k < 2 && rc == VOF_OK; ++k) {
+          h->istep += 1;
+          DISPATCH_T(h, rc = enqueue_mid_step5<double>(h), rc = enqueue_mid_step5<float>(h));
+        }
+        e = hipStreamEndCapture(h->stream, &graph);
+      }
+      h->istep = istep0;
+      if (e == hipSuccess && rc == VOF_OK && graph) e = hipGraphInstantiate(&h->gxchg5[key], graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      memcpy(h->fld, keep, sizeof(keep));
+      if (e != hipSuccess || rc != VOF_OK || !h->gxchg5[key]) {
+        (void)hipGetLastError();
+        h->gxchg5[key] = nullptr;
+        h->xchg5_graph = 0;   // eager from here on
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->cstream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+          (void)hipGetLastError();
+          (void)hipStreamDestroy(h->cstream);
+          h->cstream = nullptr;
+          if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess)
+            return fail(h, VOF_EHIP, "cannot recreate the communication stream after a failed capture");
+        }
+        if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] mode-5 exchange graph capture failed (%s): eager\n", hipGetErrorString(e));
+      }
+    }
+    if (want_graph && h->xchg5_graph && h->gxchg5[key]) {
+      HIPCHK(h, hipGraphLaunch(h->gxchg5[key], h->stream));
+      h->istep += 2;
+      h->xchg_steps += 2;
+      h->xchg_graph_steps += 2;
+    } else {
+      if ((rc = eager_mid())) return rc;
+      if ((rc = eager_mid())) return rc;
+    }
+    mid -= 2;
+  }
+  // tail
+  h->istep += 1;
+  DISPATCH_T(h, rc = enqueue_tail_step5<double>(h), rc = enqueue_tail_step5<float>(h));
+  if (rc) return rc;
+  h->xchg_steps += 1;
+  h->ghosts_virtual = h->virtual_ghosts != 0;
+  return ensure_ok(h);
+}
+
 int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
-  if (!h || nsteps < 0 || overlap < 0 || overlap > 4 || overlap == 2) return VOF_EINVAL;   // (2 was retired: never worth it)
+  if (!h || nsteps < 0 || overlap < 0 || overlap > 5 || overlap == 2) return VOF_EINVAL;   // (2 was retired: never worth it)
   if (!h->comm) return fail(h, VOF_ESTATE, "vof_comm_init has not been called");
   if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
   HIPCHK(h, hipSetDevice(h->device));
+  if (overlap == 5) return step_exchange_mode5(h, nsteps);
   const bool want_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
   for (int64_t s = 0; s < nsteps; ++s) {
     // the captured step leaves the ghost cells virtual (if the handle does that at all); every other

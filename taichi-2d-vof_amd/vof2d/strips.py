@@ -29,6 +29,7 @@ from . import _abi
 from .engine import Engine, make_desc
 
 EXCHANGED = ("F", "u", "v", "p")
+EXCHANGED_MODE5 = ("u_star", "v_star")      # next to F and p: the exchange state with the step boundary behind the predictor
 
 
 def partition(nx, world):
@@ -177,7 +178,7 @@ class StripSolver:
         torch = self.torch
         tdt = torch.float64 if self.eng.np_dtype == np.float64 else torch.float32
         typestr = "<f8" if self.eng.np_dtype == np.float64 else "<f4"
-        for f in EXCHANGED:
+        for f in EXCHANGED + EXCHANGED_MODE5:
             base, pitch, col0, nrows = self.eng.field_view(f)
             if self.on_gpu:
                 t = torch.as_tensor(_DevArray(base, (nrows, pitch), typestr), device=self.device)
@@ -255,6 +256,8 @@ class StripSolver:
             # first, one send/recv group per step), an int = that mode of vof_step_exchange
             self.eng.step_exchange(nsteps, 4 if overlap is True else int(overlap))
             return
+        if self.world > 1 and overlap == 5 and overlap is not True:
+            return self._step_boundary_behind_the_predictor(nsteps)
         with self._ctx():
             for _ in range(nsteps):
                 if self.world == 1:
@@ -272,6 +275,37 @@ class StripSolver:
                     for w in works:
                         w.wait()
 
+    def _step_boundary_behind_the_predictor(self, nsteps):
+        """The torch carrier's form of overlap mode 5 (verb by verb: what the gloo tests drive; on the GPU the library runs
+        it with its pair kernels, vof_step_exchange).  The step boundary moves behind the momentum predictor of the NEXT
+        step (2dvof.py:513-517), so that what crosses a strip edge once per step is F, p and u*, v* -- the inputs of the
+        ten sweeps and of the transport -- instead of F, u, v, p; u and v are exchanged only at the end of the call.
+        (The library's kernels recompute rho, nu from F per cell and ship rhs with u*, v*; here rho and nu are fields, so F
+        travels in front of cal_nu_rho.)"""
+        e = self.eng
+        first = e.istep + 1
+
+        def predictor():
+            e.cal_nu_rho(); e.get_normal_young(); e.advect_upwind(); e.set_BC()      # :513-518 of the coming step
+            for w in self._exchange_async(EXCHANGED_MODE5):
+                w.wait()
+
+        def pressure_and_transport(istep):
+            e.solve_p_jacobi(self.halo - 8)                                         # :521-522 (jacobi_iters sweeps)
+            e.update_uv(); e.set_BC(); e.solve_VOF_rudman(istep); e.post_process_f(); e.set_BC()   # :524-528
+
+        with self._ctx():
+            predictor()
+            for k in range(nsteps):
+                pressure_and_transport(first + k)
+                if k < nsteps - 1:
+                    for w in self._exchange_async(("F", "p")):
+                        w.wait()
+                    predictor()
+            e.istep = first + nsteps - 1
+            for w in self._exchange_async(EXCHANGED):
+                w.wait()
+
     def solve_p(self, tol, max_iters, check_every=10, criterion="abs"):
         """Extension: Jacobi until the GLOBAL residual <= tol -- "abs": max|p_new - p|, "rel": that
         over max(max|p_new|, tiny) -- both norms all-reduced (MAX) over the ranks.  With strips the
@@ -279,7 +313,7 @@ class StripSolver:
         it serve the sweeps), so a check covers at most that many sweeps.  Same sweep counts and
         the same rule as vof_solve_p on a single domain: n = min(check_every, max_iters - done)."""
         crit = {"abs": _abi.VOF_RESID_ABS, "rel": _abi.VOF_RESID_REL}[criterion]
-        depth = self.halo - 6           # sweeps the deep halo of p covers between two exchanges
+        depth = self.halo - 8           # sweeps the deep halo of p covers between two exchanges
         if self.world > 1 and depth < 1:
             raise ValueError("solve_p on strips needs jacobi_iters >= 1 (the halo of p covers jacobi_iters sweeps "
                              "between two exchanges; this solver was made with jacobi_iters = %d)" % depth)

@@ -153,11 +153,62 @@ def exchange_mode4_equals_phases_plus_copies(hip_api, own):
     e.comm_destroy(); e.close(); ref.close()
 
 
+def exchange_mode5_equals_pieces_plus_copies(hip_api, own):
+    """vof_step_exchange overlap 5 (the strips run k_jacobi_pair and k_tm; F, u*, v*, rhs, p exchanged once per step, the
+    edge bands of k_tm on the communication stream in front of the send / recv group, the other rows beside them) with the
+    neighbours looped back: the middle steps replayed from captured graphs, two per launch, must equal the same kernels
+    piece by piece (vof_step_tm_piece) with hand-made halo copies, on every stored row, ghost cells included."""
+    from vof2d import _abi
+    from vof2d.engine import Engine, make_desc, comm_unique_id
+    nx, ny, W = 200, 96, _abi.halo_rows(10)
+    rows = (max(0, own[0] - W), min(nx + 1, own[1] + W))
+    wall_lo, wall_hi = own[0] == 1, own[1] == nx
+    e = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
+    ref = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
+    for x in (e, ref):
+        x.set_init_F(3)
+    e.comm_init(comm_unique_id(hip_api), 0, 1, loopback=True)
+    lo, hi = own[0] - rows[0], own[1] - rows[0]
+
+    def loop(fields):
+        for f in fields:
+            a = ref.get(f, rows)
+            if not wall_lo:
+                a[lo - W:lo] = a[lo:lo + W]
+            if not wall_hi:
+                a[hi + 1:hi + 1 + W] = a[hi - W + 1:hi + 1]
+            ref.set(f, a, rows)
+        ref.set_BC()      # (set marked the ghost cells of F, u, v unknown; they are the copied rows' own: settle them)
+
+    for n in (1, 4, 7, 2, 1, 12):   # the first step of a communicator is eager and runs as mode 1
+        first = e.istep == 0
+        e.step_exchange(n, 5)
+        if first:
+            for ph in (0, 1, 2):
+                ref.step_phase(ph)
+            loop(("p", "u", "v", "F"))
+            n -= 1
+        if n > 0:
+            ref.step_tm_piece(0); loop(("u_star", "v_star", "rhs"))
+            for _ in range(n - 1):
+                ref.step_tm_piece(1); loop(("F", "u_star", "v_star", "rhs", "p"))
+            ref.step_tm_piece(2); loop(("p", "u", "v", "F"))
+        assert e.istep == ref.istep
+        assert e.comm_info()[1] == 1, "exchange graph capture unavailable (RCCL %d)" % e.comm_info()[0]
+        for f in ("F", "u", "v", "p"):
+            got, want = e.get(f, rows), ref.get(f, rows)
+            assert np.array_equal(got, want, equal_nan=True), (own, f, int(e.istep), np.argwhere(got != want)[:4])
+    assert e.get_counter("exchange_graph_steps") >= 2 + 6 + 10      # the middle steps, two per launch
+    e.comm_destroy(); e.close(); ref.close()
+
+
 if __name__ == "__main__":
     from vof2d._lib import hip_api as load
     api = load()
     if sys.argv[1] == "modes":
         native_rccl_exchange_loopback(api)
+    elif sys.argv[1] == "mode5":
+        exchange_mode5_equals_pieces_plus_copies(api, (int(sys.argv[2]), int(sys.argv[3])))
     else:
         exchange_mode4_equals_phases_plus_copies(api, (int(sys.argv[2]), int(sys.argv[3])))
     assert "torch" not in sys.modules, "the worker must stay torch-free"

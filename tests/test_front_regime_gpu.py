@@ -178,3 +178,56 @@ def test_batch_form_follows_a_rule_on_the_state(hip_api):
     for e in (c, d):
         e.step(20)
         assert e.get_counter("tm_choice") == -1 and e.get_counter("tm_steps") == 0
+
+
+@pytest.mark.parametrize("nstrips", [2, 8])
+def test_strips_run_the_pair_kernels_inside_the_front(hip_api, nstrips):
+    """Overlap mode 5 of vof_step_exchange, piece by piece (vof_step_tm_piece) with device copies standing in for the
+    send / recv groups: the strips run k_jacobi_pair and k_tm (this step's transport + the next step's momentum), the
+    step boundary sits behind the momentum predictor and ONE exchange per step carries F, u*, v*, rhs, p,
+    VOF_HALO_ROWS deep.  2048^2 fp64 dam-break, calls of 7, 12 and 1 steps, checked against the single domain on the owned
+    rows while the tiny-value front crosses the strips (each strip plans its pairs' chunks from its own reports)."""
+    from vof2d.strips import partition, stored_rows
+    n, W = 2048, halo_rows(10)
+    full = engine(hip_api, n, n, "f64", "f32", ic=1)
+    owns = partition(n, nstrips)
+    strips = [engine(hip_api, n, n, "f64", "f32", ic=1, rows=stored_rows(n, o, W), own=o) for o in owns]
+
+    def trade(fields):
+        for k in range(nstrips - 1):
+            lo_s, hi_s = strips[k], strips[k + 1]
+            edge = owns[k][1]
+            for f in fields:
+                lo_s.copy_rows_from(hi_s, f, edge + 1, edge + W)
+                hi_s.copy_rows_from(lo_s, f, edge + 1 - W, edge)
+
+    full.step(1)
+    for s in strips:
+        s.step(1)                                    # (the first step after set_init_F: the reference's set_BC calls)
+    trade(STATE)
+    planned = [0] * nstrips
+    done = 1
+    for call in (7, 12, 30, 1, 29, 40):
+        full.step(call)
+        for s in strips:
+            s.step_tm_piece(0)
+        trade(("u_star", "v_star", "rhs"))
+        for _ in range(call - 1):
+            for s in strips:
+                s.step_tm_piece(1)
+            trade(("F", "u_star", "v_star", "rhs", "p"))
+            for k, s in enumerate(strips):
+                planned[k] += s.get_counter("tb_plan_active")
+        for s in strips:
+            s.step_tm_piece(2)
+        trade(STATE)
+        done += call
+        assert all(s.istep == done for s in strips) and full.istep == done
+        if done >= 50:
+            assert _tiny_cells(full.get("p")) > 10000
+        for k, s in enumerate(strips):
+            g0 = 0 if k == 0 else owns[k][0]
+            g1 = n + 1 if k == nstrips - 1 else owns[k][1]
+            assert_fields_same(s, full, STATE, rows=(g0, g1), ctx="step %d strip %d of %d (pair kernels)" % (done, k, nstrips))
+    assert done == 120 and sum(1 for x in planned if x > 10) >= nstrips // 2, planned     # most strips met the front and planned their pairs
+    assert sum(s.get_counter("courant_violations") for s in strips) == full.get_counter("courant_violations")

@@ -118,6 +118,13 @@ def test_exchange_mode4_equals_phases_plus_copies(own):
     _loopback_worker("mode4", own[0], own[1])
 
 
+@pytest.mark.parametrize("own", [(61, 140), (1, 100), (101, 200), (90, 117)])
+def test_exchange_mode5_equals_pieces_plus_copies(own):
+    """vof_step_exchange overlap 5 -- the strips run the pair kernels of the single GPU, F, u*, v*, rhs, p exchanged once
+    per step -- replayed from captured graphs on an interior strip, next to either wall and on a strip whose bands meet."""
+    _loopback_worker("mode5", own[0], own[1])
+
+
 def test_command_line_residual_terminated_solve(tmp_path):
     """2dvof.py --jacobi-tol / --jacobi-crit (extension): the main loop :513-528 with vof_solve_p in place of
     the ten fixed sweeps runs headless and reports like the reference."""

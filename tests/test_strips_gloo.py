@@ -22,7 +22,7 @@ def test_partition_covers_the_grid():
         assert max(sizes) - min(sizes) <= 1
     assert stored_rows(64, (1, 32), 16) == (0, 48)
     assert stored_rows(64, (33, 64), 16) == (17, 65)
-    assert halo_rows(10) == 16
+    assert halo_rows(10) == 18
 
 
 def test_balanced_partition_equalises_the_measured_cost():
@@ -69,11 +69,14 @@ def _free_port():
 
 @pytest.mark.parametrize("nx,ny,ic,dtype,world,overlap", [
     (72, 40, 1, "f64", 2, True), (72, 40, 1, "f64", 2, False), (66, 24, 2, "f32", 2, True),
-    (96, 20, 3, "f64", 3, True), (128, 33, 1, "f64", 4, True)])
+    (96, 20, 3, "f64", 3, True), (128, 33, 1, "f64", 4, True),
+    (72, 40, 1, "f64", 2, 5), (96, 20, 3, "f64", 3, 5), (66, 24, 2, "f32", 2, 5)])
 def test_strips_equal_single_domain(oracle_api, tmp_path, nx, ny, ic, dtype, world, overlap):
     """overlap=True: the phased step with each field's halo sent as soon as it is final, the
     transfers running concurrently (gloo threads here, RCCL's stream on the GPU) with the rest of
-    the step; overlap=False: one exchange after the whole step.  Both must equal the single domain."""
+    the step; overlap=False: one exchange after the whole step; overlap=5: the exchange state of the pair kernels -- the
+    step boundary behind the next step's predictor, F, p and u*, v* across the strip edges once per step, u and v only at
+    the end of a call.  All must equal the single domain."""
     import torch.multiprocessing as mp
     import _strip_worker
     steps = 12
