@@ -475,7 +475,9 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
                                             const T* __restrict__ us, const T* __restrict__ vs, const T* __restrict__ p,
                                             T* __restrict__ Uo, T* __restrict__ Vo, T* __restrict__ us_out,
                                             T* __restrict__ vs_out, T* __restrict__ rhs,
-                                            unsigned long long* __restrict__ courant, int R, TbPlan tp, int first, int last) {
+                                            unsigned long long* __restrict__ courant, int R, TbPlan tp, int first, int last,
+                                            int first2 = 1, int last2 = 0) {
+  // rows [first, last] and -- the two edge bands of a strip in one launch -- [first2, last2] (last2 < first2: none), each cut in chunks of R
   constexpr int W = 64 * V, HF = TmGeom::HF, STRIDE = W - 2 * HF;
   static_assert(HF >= 4 + 3 && HF % V == 0, "momentum's inputs must lie inside the transport march's valid columns");
   static_assert(sizeof(TbPlanShared) <= sizeof(TmRing<double, 2>) / 2, "the planner block borrows the ring's LDS");
@@ -492,9 +494,14 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
   const int lane = threadIdx.x & 63;
   const int tj = pair % ntf, ch = pair / ntf;
   const int c0 = 1 - HF + tj * STRIDE;
-  const int ma = first + ch * R;
-  if (ma > last) return;   // (block-uniform: both waves leave)
-  const int mb = ma + R - 1 < last ? ma + R - 1 : last;
+  int ma = first + ch * R, lim = last;
+  if (ma > last) {         // (block-uniform)
+    const int n1 = last >= first ? (last - first + R) / R : 0;
+    ma = first2 + (ch - n1) * R;
+    lim = last2;
+    if (last2 < first2 || ma > last2) return;   // both waves leave
+  }
+  const int mb = ma + R - 1 < lim ? ma + R - 1 : lim;
   // interior pair: rows ma - 6 .. mb + 6 in [3, nx - 1], columns c0 - 1 .. c0 + W in [1, ny + 1] with every lane's columns in [2, ny]
   // (on a strip also inside the stored rows: the interior marches do not clamp their row addresses)
   const bool interior = ma >= 9 && mb + 7 <= g.nx && ma - 6 >= g.row_lo && mb + 7 <= g.row_hi && c0 >= 2 && c0 + W - 1 <= g.ny;

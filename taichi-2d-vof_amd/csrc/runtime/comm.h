@@ -99,10 +99,14 @@ void destroy_xchg_graphs(vof2d_ctx* h) {
 }
 // (s_in_alt: between the launches of k_tm and the host's swap the new u*, v* still live in the mx / my arrays;
 // on_cstream: whatever the messages wait for was enqueued on the communication stream itself)
-int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1, bool s_in_alt = false, bool on_cstream = false) {
+constexpr int kTmBandRows = 6;    // rows per pair chunk of k_tm's edge-band launch
+constexpr int kTmReachRows = 8;   // halo rows of F, u*, v* the marches of k_tm read beyond the owned rows (3 + 3 + 1: x pipeline, momentum window, faces)
+// shallow: F, u*, v* travel kTmReachRows deep only (mode 5's middle steps: all k_tm reads of them; p and rhs serve the ten
+// sweeps in front of it and travel W deep)
+int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1, bool s_in_alt = false, bool on_cstream = false, bool shallow = false) {
   Rccl* r = rccl();
   const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
-  const size_t row_bytes = (size_t)h->g.pitch * h->esz, bytes = (size_t)W * row_bytes;
+  const size_t row_bytes = (size_t)h->g.pitch * h->esz;
   if (!on_cstream) {
     hipEvent_t ready = fork >= 0 ? h->ev_fork[fork] : h->ev_ready;
     HIPCHK(h, hipEventRecord(ready, h->stream));
@@ -121,12 +125,14 @@ int comm_post(vof2d_ctx* h, unsigned mask, bool f_in_twin = false, int fork = -1
     const int id = (k == 0 && f_in_twin) ? fF2 : (k == 4 && s_in_alt) ? fMX : (k == 5 && s_in_alt) ? fMY : ids[k];
     char* base = reinterpret_cast<char*>(h->fld[id]);
     auto row = [&](int g) { return base + (size_t)(g - h->d.row_lo) * row_bytes; };
+    const int D = (shallow && (k == 0 || k == 4 || k == 5) && kTmReachRows < W) ? kTmReachRows : W;   // rows of this field
+    const size_t bytes = (size_t)D * row_bytes;
     if (h->peer_lo >= 0) {
       note(r->Send(row(h->d.own_lo), bytes, /*ncclInt8*/ 0, h->peer_lo, h->comm, h->cstream), "ncclSend(lo)");
-      note(r->Recv(row(h->d.own_lo - W), bytes, 0, h->peer_lo, h->comm, h->cstream), "ncclRecv(lo)");
+      note(r->Recv(row(h->d.own_lo - D), bytes, 0, h->peer_lo, h->comm, h->cstream), "ncclRecv(lo)");
     }
     if (h->peer_hi >= 0) {
-      note(r->Send(row(h->d.own_hi - W + 1), bytes, 0, h->peer_hi, h->comm, h->cstream), "ncclSend(hi)");
+      note(r->Send(row(h->d.own_hi - D + 1), bytes, 0, h->peer_hi, h->comm, h->cstream), "ncclSend(hi)");
       note(r->Recv(row(h->d.own_hi + 1), bytes, 0, h->peer_hi, h->comm, h->cstream), "ncclRecv(hi)");
     }
   }
@@ -226,17 +232,18 @@ void tm5_tm(vof2d_ctx* h, int64_t istep, int part) {
   const bool y_first = (istep % 2 == 0);
   const int par_next = (int)((istep + 1) & 1);
   h->jpair_active = L<T>::jacobi_pair_ok(h);
-  auto run = [&](int a, int b, int par, int rows_forced) {
+  auto run = [&](int a, int b, int par, int rows_forced, int a2 = 1, int b2 = 0) {
+    if (b < a) { a = a2; b = b2; a2 = 1; b2 = 0; }
     if (b < a) return;
-    if (y_first) L<T>::template tm<true, false>(h, par, a, b, rows_forced); else L<T>::template tm<false, false>(h, par, a, b, rows_forced);
+    if (y_first) L<T>::template tm<true, false>(h, par, a, b, rows_forced, a2, b2); else L<T>::template tm<false, false>(h, par, a, b, rows_forced, a2, b2);
   };
   const bool split = o.in_lo <= o.in_hi && (o.band_lo || o.band_hi);
   if (part == 0 || !split) {
     if (part == 0 || (part == 1 && (o.band_lo || o.band_hi)) || (part == 2 && !(o.band_lo || o.band_hi))) run(o.lo, o.hi, par_next, 0);   // (one launch for the step: it carries the planner block)
   } else if (part == 1) {
-    const int W = VOF_HALO_ROWS(h->d.jacobi_iters);
-    if (o.band_lo) run(o.lo, o.in_lo - 1, -1, W);
-    if (o.band_hi) run(o.in_hi + 1, o.hi, -1, W);
+    // both bands in ONE launch, in short chunks (a pair's march is its rows + 14 steps whatever its rows: the bands are
+    // what the send / recv group waits for -- 8192-wide interior strip of 8: two launches of 18-row chunks 56 + 69 us)
+    run(o.band_lo ? o.lo : 1, o.band_lo ? o.in_lo - 1 : 0, -1, kTmBandRows, o.band_hi ? o.in_hi + 1 : 1, o.band_hi ? o.hi : 0);
   } else {
     run(o.in_lo, o.in_hi, par_next, 0);
   }
@@ -255,7 +262,7 @@ int enqueue_mid_step5(vof2d_ctx* h) {
   h->stream = h->cstream;
   tm5_tm<T>(h, h->istep, 1);
   h->stream = st;
-  if ((rc = comm_post(h, VOF_XCHG_F | VOF_XCHG_US | VOF_XCHG_VS | VOF_XCHG_RHS | VOF_XCHG_P, /*f_in_twin=*/true, 1, /*s_in_alt=*/true, /*on_cstream=*/true))) return rc;
+  if ((rc = comm_post(h, VOF_XCHG_F | VOF_XCHG_US | VOF_XCHG_VS | VOF_XCHG_RHS | VOF_XCHG_P, /*f_in_twin=*/true, 1, /*s_in_alt=*/true, /*on_cstream=*/true, /*shallow=*/true))) return rc;
   tm5_tm<T>(h, h->istep, 2);
   swap_F(h);
   swap_S(h);

@@ -28,7 +28,7 @@ void dbg_tm(vof2d_ctx* h) {
   const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf);
   launch_block(h, kTM, k_tm<T, V, YFIRST, false, true, ABL>, dim3(pairs), 128u, 0, h->g, L<T>::C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
                (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
-               F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant + 3, R, tp, first, last);
+               F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant + 3, R, tp, first, last, 1, 0);
 }
 
 }  // namespace

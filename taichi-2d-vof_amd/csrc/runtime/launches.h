@@ -396,7 +396,7 @@ struct L {
     return (int)(R < 16 ? 16 : (R > 96 ? 96 : R));
   }
   template <bool YFIRST, bool STORE_UV>
-  static void tm(vof2d_ctx* h, int adapt_par, int first = 1, int last = 0, int rows_forced = 0) {
+  static void tm(vof2d_ctx* h, int adapt_par, int first = 1, int last = 0, int rows_forced = 0, int first2 = 1, int last2 = 0) {
     if (last < first) { first = h->g.ilo; last = h->g.ihi; }
     constexpr int ST = 64 * V - 2 * TmGeom::HF;
     const int ntf = (h->g.ny + ST - 1) / ST;
@@ -407,16 +407,16 @@ struct L {
     // 100 376 / 381 (tools/probes/pair_bound.py --rows)
     const int R = rows_forced > 0 ? rows_forced : tm_chunk_rows(h, last - first + 1, ntf, resident_blocks(h, k_tm<T, V, YFIRST, STORE_UV, true>, 128));
     const TbPlan tp = tb_plan(h, adapt_par);
-    const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf) + (tp.masks ? 1u : 0u);
+    const unsigned pairs = (unsigned)((((last - first + R) / R) + (last2 >= first2 ? (last2 - first2 + R) / R : 0)) * ntf) + (tp.masks ? 1u : 0u);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 4);
     if (bs)
       launch_block(h, kTM, k_tm<T, V, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
-             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last);
+             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2);
     else
       launch_block(h, kTM, k_tm<T, V, YFIRST, STORE_UV, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
-             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last);
+             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2);
   }
   // update_uv + both sweeps + post_process_f in one pass (k_transport); reads fld[fF], writes fld[fF2]
   static int transport_rows(const vof2d_ctx* h) {

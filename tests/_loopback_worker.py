@@ -170,13 +170,13 @@ def exchange_mode5_equals_pieces_plus_copies(hip_api, own):
     e.comm_init(comm_unique_id(hip_api), 0, 1, loopback=True)
     lo, hi = own[0] - rows[0], own[1] - rows[0]
 
-    def loop(fields):
+    def loop(fields, D=W):
         for f in fields:
             a = ref.get(f, rows)
             if not wall_lo:
-                a[lo - W:lo] = a[lo:lo + W]
+                a[lo - D:lo] = a[lo:lo + D]
             if not wall_hi:
-                a[hi + 1:hi + 1 + W] = a[hi - W + 1:hi + 1]
+                a[hi + 1:hi + 1 + D] = a[hi - D + 1:hi + 1]
             ref.set(f, a, rows)
         ref.set_BC()      # (set marked the ghost cells of F, u, v unknown; they are the copied rows' own: settle them)
 
@@ -191,7 +191,9 @@ def exchange_mode5_equals_pieces_plus_copies(hip_api, own):
         if n > 0:
             ref.step_tm_piece(0); loop(("u_star", "v_star", "rhs"))
             for _ in range(n - 1):
-                ref.step_tm_piece(1); loop(("F", "u_star", "v_star", "rhs", "p"))
+                # (p and rhs travel W deep -- the ten sweeps --, F, u*, v* as deep as k_tm reads them: a looped-back neighbour is a
+                # translate of the strip by the depth of the message)
+                ref.step_tm_piece(1); loop(("rhs", "p")); loop(("F", "u_star", "v_star"), 8)
             ref.step_tm_piece(2); loop(("p", "u", "v", "F"))
         assert e.istep == ref.istep
         assert e.comm_info()[1] == 1, "exchange graph capture unavailable (RCCL %d)" % e.comm_info()[0]

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--n", type=int, default=8); ap.add_argument("--nx", type=int, default=8192)
     ap.add_argument("--ny", type=int, default=8192); ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--dt", type=float, default=1e-6)
-    ap.add_argument("--modes", default="compute,native-overlap,native-two,native-after,native-fused")
+    ap.add_argument("--modes", default="compute,native-overlap,native-two,native-after,native-fused,compute-pairs,native-pairs")
     ap.add_argument("--rounds", type=int, default=2)
     a = ap.parse_args()
     modes = a.modes.split(",")
@@ -43,6 +43,7 @@ def main():
         stream_ptr = stream.cuda_stream
     e = Engine(api, make_desc(api, a.nx, a.ny, "f64", "f32", rows=rows, own=own, device=0, dt=a.dt), stream=stream_ptr)
     e.set_init_F(1)
+    e.step(1)                  # (the first step after set_init_F: the schedule with the reference's intermediate set_BC calls)
     e.comm_init(comm_unique_id(api), 0, 1, loopback=True)
     print("RCCL version code %d, exchange graphs %s" % e.comm_info())
     lo, hi = own[0] - rows[0], own[1] - rows[0]
@@ -72,6 +73,13 @@ def main():
             e.step_exchange(n, 0)
         elif mode == "native-fused":
             e.step_exchange(n, 4)
+        elif mode == "native-pairs":          # overlap mode 5: k_jacobi_pair + k_tm, F u* v* rhs p once per step
+            e.step_exchange(n, 5)
+        elif mode == "compute-pairs":         # ... its kernels without the exchange
+            e.step_tm_piece(0)
+            for _ in range(n - 1):
+                e.step_tm_piece(1)
+            e.step_tm_piece(2)
         else:
             with torch.cuda.stream(stream):
                 for _ in range(n):

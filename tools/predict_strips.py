@@ -22,6 +22,47 @@ sys.path.insert(0, os.path.join(ROOT, "taichi-2d-vof_amd"))
 STATE = ("F", "u", "v", "p")
 
 
+MODE5 = ("F", "u_star", "v_star", "rhs", "p")
+
+
+def strip_costs_pairs(api, nx, dtype, dt, parts, W, steps, skip=3):
+    """The same for overlap mode 5 (the strips run k_jacobi_pair and k_tm, vof_step_tm_piece): ms per MIDDLE step of each
+    strip's own kernels, its halos of F, u*, v*, rhs, p refreshed after every step from a full domain driven through the
+    same pieces."""
+    from vof2d.engine import Engine, make_desc
+    from vof2d.strips import stored_rows
+    costs = []
+    for r, own in enumerate(parts):
+        full = Engine(api, make_desc(api, nx, nx, dtype, "f32", device=0, dt=dt))
+        rows = stored_rows(nx, own, W)
+        s = Engine(api, make_desc(api, nx, nx, dtype, "f32", rows=rows, own=own, device=0, dt=dt))
+
+        def refresh(fields):
+            for f in fields:                     # what the neighbours would send
+                if rows[0] < own[0]:
+                    s.copy_rows_from(full, f, rows[0], own[0] - 1)
+                if rows[1] > own[1]:
+                    s.copy_rows_from(full, f, own[1] + 1, rows[1])
+        for x in (full, s):
+            x.set_init_F(1)
+            x.step(1)
+        refresh(STATE)
+        for x in (full, s):
+            x.step_tm_piece(0)
+        refresh(("u_star", "v_star", "rhs"))
+        ms = []
+        for k in range(steps):
+            s.timer_start()
+            s.step_tm_piece(1)
+            ms.append(s.timer_stop())
+            full.step_tm_piece(1)
+            refresh(MODE5)
+        costs.append(sum(ms[skip:]) / len(ms[skip:]))
+        s.close()
+        full.close()
+    return costs
+
+
 def strip_costs(api, nx, dtype, dt, parts, W, steps, skip=3):
     """ms per step of each strip's own kernels (device timer), halos refreshed from a full-domain run."""
     from vof2d.engine import Engine, make_desc
@@ -56,7 +97,9 @@ def main():
     ap.add_argument("--ranks", default="2,4,8")
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--pairs", action="store_true", help="overlap mode 5: the strips run k_jacobi_pair and k_tm (middle steps of a call)")
     a = ap.parse_args()
+    costs_of = strip_costs_pairs if a.pairs else strip_costs
     from vof2d import _abi
     from vof2d._lib import hip_api
     from vof2d.engine import Engine, make_desc
@@ -75,13 +118,20 @@ def main():
     print("|---|---|---|---|---|---|")
     for n in [int(x) for x in a.ranks.split(",")]:
         parts = partition(nx, n)
-        c = strip_costs(api, nx, a.dtype, dt, parts, W, a.steps)
+        c = costs_of(api, nx, a.dtype, dt, parts, W, a.steps)
         print("| %d | equal | %s | %s | %.3f | %.2f |" % (n, " ".join(str(hi - lo + 1) for lo, hi in parts), " ".join("%.3f" % x for x in c), max(c), one / max(c)))
         if max(c) > 1.015 * sum(c) / len(c):
             parts2 = balanced_partition(nx, parts, c, min_rows=W)
-            c2 = strip_costs(api, nx, a.dtype, dt, parts2, W, a.steps)
+            c2 = costs_of(api, nx, a.dtype, dt, parts2, W, a.steps)
             print("| %d | balanced (as bench.py re-cuts it) | %s | %s | %.3f | %.2f |" % (n, " ".join(str(hi - lo + 1) for lo, hi in parts2), " ".join("%.3f" % x for x in c2), max(c2), one / max(c2)))
         sys.stdout.flush()
+    if a.pairs:
+        print("\nThe per-rank figures are the middle steps of an overlap-mode-5 call (steps 5-%d of the run): k_jacobi_pair on all"
+              "\nstored rows and k_tm (this step's transport + the next step's momentum) on the owned rows as ONE launch, kernels only,"
+              "\ndevice-timed.  vof_step_exchange runs k_tm as two concurrent launches (edge bands on the communication stream in front"
+              "\nof the send / recv group, the other rows beside them); the head and the tail of a call (k_momentum; two k_jacobi_tb +"
+              "\nk_transport) are paid once per call of n steps." % (a.steps + 1))
+        return
     print("\nThe per-rank figures are the first steps of the run (steps 4-%d): kernels only, device-timed; the strips run the"
           "\ntwo-kernel transport here (vof_step on a strip handle), the RCCL path (vof_step_exchange mode 4) the fused one on the"
           "\nedge bands and the inner rows, which `profiles/r03e_strip_exchange.md` measured 5-6 %% faster for the interior strip of 8."
