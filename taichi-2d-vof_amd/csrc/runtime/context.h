@@ -182,6 +182,7 @@ struct vof2d_ctx {
   bool tm_broken = false;    // the k_tm batch graphs could not be captured: the other form stays
   int jpair = 1;             // knob "jacobi_pair": the k_tm batch graphs run each two five-sweep launches as one k_jacobi_pair launch
   int jpair_rows = 0;        // rows per pair chunk (0 = one residency round of pairs)
+  int pair_vec4 = 0;         // knob "pair_vec4": fp32 pair kernels with four columns per lane (256-column tiles)
   bool jpair_active = false; // the launches being enqueued are k_jacobi_pair's (tb_plan describes their geometry)
   bool jpair_captured = false;   // the k_tm batch graphs the handle holds contain k_jacobi_pair launches
   int64_t pair_launches = 0; // k_jacobi_pair launches replayed (counter "pair_launches")

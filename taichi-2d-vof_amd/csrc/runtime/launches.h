@@ -247,27 +247,56 @@ struct L {
     return (h->jpair > 1 || (h->jpair == 1 && sizeof(T) == 8)) && cc.dxi2 == cc.dyi2 && !h->tb_general && h->tb >= 5 &&
            h->d.jacobi_iters % 10 == 0;
   }
-  static int jacobi_pair_geom(vof2d_ctx* h, int& ntt) {
-    constexpr int ST = 64 * V - 2 * (((2 * 5 + V - 1) / V) * V);   // must match the kernel: 108 columns
+  // Columns per lane of the pair kernels: 2, or -- fp32, knob "pair_vec4" -- 4: a lane then moves the 16 bytes per row the fp64
+  // kernels move, a tile is 256 columns (232 / 240 of them stored instead of 108 / 112 of 128), and the cross-lane moves and the
+  // scalar bookkeeping of a row serve twice the cells.
+  // EXPERIMENT (make variant NAME=vec4 EXTRA=-DVOF_PAIR_VEC4, then knob pair_vec4 = 1; tools/probes/forms_ab.py): same values,
+  // 128 / 135-149 VGPRs (four / three waves per SIMD) -- and 4096^2 fp32 0.62 ms/step against 0.35 with two columns per lane
+  // and 0.33 for the chains: a pair's step lasts as long as its longer wave's instructions, and a wave now carries twice as
+  // many.  The product does not instantiate it.
+  static int pair_vec(const vof2d_ctx* h) {
+#ifdef VOF_PAIR_VEC4
+    return (sizeof(T) == 4 && h->pair_vec4 && h->g.ny % 4 == 0 && buffer_stores_ok(h)) ? 4 : V;
+#else
+    (void)h;
+    return V;
+#endif
+  }
+  template <int VV>
+  static int jacobi_pair_geom_v(vof2d_ctx* h, int& ntt) {
+    constexpr int ST = 64 * VV - 2 * (((2 * 5 + VV - 1) / VV) * VV);   // must match the kernel: 108 columns (232 with four per lane)
     ntt = (h->g.ny + ST - 1) / ST;
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 2);
-    const long cap = bs ? resident_blocks(h, k_jacobi_pair<T, V, 5, true>, 128) : resident_blocks(h, k_jacobi_pair<T, V, 5, false>, 128);
+    const long cap = bs ? resident_blocks(h, k_jacobi_pair<T, VV, 5, true>, 128) : resident_blocks(h, k_jacobi_pair<T, VV, 5, false>, 128);
     return h->jpair_rows > 0 ? h->jpair_rows : chunk_rows_fit(h, ntt, cap, 8, 160);
   }
+  static int jacobi_pair_geom(vof2d_ctx* h, int& ntt) {
+#ifdef VOF_PAIR_VEC4
+    if constexpr (sizeof(T) == 4) { if (pair_vec(h) == 4) return jacobi_pair_geom_v<4>(h, ntt); }
+#endif
+    return jacobi_pair_geom_v<V>(h, ntt);
+  }
   // ten sweeps src -> dst
-  static void jacobi_pair(vof2d_ctx* h, int src, int dst, int adapt_par = -1, int first = 1, int last = 0) {
-    if (last < first) { first = h->g.ilo; last = h->g.ihi; }
+  template <int VV>
+  static void jacobi_pair_v(vof2d_ctx* h, int src, int dst, int adapt_par, int first, int last) {
     int ntt = 0;
-    const int R = jacobi_pair_geom(h, ntt);
+    const int R = jacobi_pair_geom_v<VV>(h, ntt);
     const TbPlan tp = tb_plan(h, adapt_par);
     const unsigned pairs = tp.masks ? (unsigned)tp.waves : (unsigned)(((last - first + R) / R) * ntt);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 2);
     if (bs)
-      launch_block(h, kJacobiPair, k_jacobi_pair<T, V, 5, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
+      launch_block(h, kJacobiPair, k_jacobi_pair<T, VV, 5, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
                    (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last);
     else
-      launch_block(h, kJacobiPair, k_jacobi_pair<T, V, 5, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
+      launch_block(h, kJacobiPair, k_jacobi_pair<T, VV, 5, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
                    (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last);
+  }
+  static void jacobi_pair(vof2d_ctx* h, int src, int dst, int adapt_par = -1, int first = 1, int last = 0) {
+    if (last < first) { first = h->g.ilo; last = h->g.ihi; }
+#ifdef VOF_PAIR_VEC4
+    if constexpr (sizeof(T) == 4) { if (pair_vec(h) == 4) return jacobi_pair_v<4>(h, src, dst, adapt_par, first, last); }
+#endif
+    jacobi_pair_v<V>(h, src, dst, adapt_par, first, last);
   }
   // the work plan of the step's five-sweep launches (see tb_make_plan): active on parity-keyed step
   // sequences (adapt_par = istep & 1), square or not, two columns per lane, up to TB_COLS tile columns
@@ -398,23 +427,30 @@ struct L {
   template <bool YFIRST, bool STORE_UV>
   static void tm(vof2d_ctx* h, int adapt_par, int first = 1, int last = 0, int rows_forced = 0, int first2 = 1, int last2 = 0) {
     if (last < first) { first = h->g.ilo; last = h->g.ihi; }
-    constexpr int ST = 64 * V - 2 * TmGeom::HF;
+#ifdef VOF_PAIR_VEC4
+    if constexpr (sizeof(T) == 4) { if (pair_vec(h) == 4) return tm_v<4, YFIRST, STORE_UV>(h, adapt_par, first, last, rows_forced, first2, last2); }
+#endif
+    tm_v<V, YFIRST, STORE_UV>(h, adapt_par, first, last, rows_forced, first2, last2);
+  }
+  template <int VV, bool YFIRST, bool STORE_UV>
+  static void tm_v(vof2d_ctx* h, int adapt_par, int first, int last, int rows_forced, int first2, int last2) {
+    constexpr int ST = 64 * VV - 2 * TmGeom::HF;
     const int ntf = (h->g.ny + ST - 1) / ST;
     // pair chunks: a whole number of residency rounds, just filled (6 pairs per CU: 24 KB of LDS each) -- a launch that needs a
     // little more than k rounds pays for k + 1 --, as many rounds as keep the chunks near 50 rows (one round of 100-row
     // chunks: every step of every pair takes 3.3 us instead of 1.9).  4096^2, 112-column tiles, us per launch: 40 rows
     // (2.5 rounds) 261 / 281 (inside / behind the front), 48 252 / 282, 52 253 / 280, 54 256 / 277, 56 257 / 284,
     // 100 376 / 381 (tools/probes/pair_bound.py --rows)
-    const int R = rows_forced > 0 ? rows_forced : tm_chunk_rows(h, last - first + 1, ntf, resident_blocks(h, k_tm<T, V, YFIRST, STORE_UV, true>, 128));
+    const int R = rows_forced > 0 ? rows_forced : tm_chunk_rows(h, last - first + 1, ntf, resident_blocks(h, k_tm<T, VV, YFIRST, STORE_UV, true>, 128));
     const TbPlan tp = tb_plan(h, adapt_par);
     const unsigned pairs = (unsigned)((((last - first + R) / R) + (last2 >= first2 ? (last2 - first2 + R) / R : 0)) * ntf) + (tp.masks ? 1u : 0u);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 4);
     if (bs)
-      launch_block(h, kTM, k_tm<T, V, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+      launch_block(h, kTM, k_tm<T, VV, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
              F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2);
     else
-      launch_block(h, kTM, k_tm<T, V, YFIRST, STORE_UV, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+      launch_block(h, kTM, k_tm<T, VV, YFIRST, STORE_UV, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
              F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2);
   }

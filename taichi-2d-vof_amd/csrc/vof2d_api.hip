@@ -65,7 +65,8 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   g.col0 = align - 1;                   // j = 1 lands on a 128-byte boundary
   // furthest column any lane touches: the overlapped tiles of k_fct_y / k_jacobi_tb start at most
   // H <= 12 columns left of j = 1 and their last tile may run a full tile past ny.
-  long maxcol = (long)d->ny + W + 16;
+  // (the fp32 pair kernels with four columns per lane: 256-column tiles)
+  long maxcol = (long)d->ny + (d->dtype == VOF_F32 ? 256 : W) + 16;
   g.pitch = ((g.col0 + maxcol + 1 + align - 1) / align) * align;
   const size_t nrows = (size_t)(d->row_hi - d->row_lo + 1);
   h->field_elems = nrows * (size_t)g.pitch + (size_t)align;  // + one 128-byte tail pad
@@ -704,7 +705,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
             : !strcmp(name, "momentum_rows") ? &h->mom_rows : !strcmp(name, "fctx_rows") ? &h->fctx_rows
             : !strcmp(name, "fctx_corr_rows") ? &h->fctx_corr_rows : !strcmp(name, "band_rows") ? &h->band_rows
             : !strcmp(name, "rows_per_wave") ? &h->rows_override : !strcmp(name, "fuse_transport") ? &h->fuse_transport
-            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : !strcmp(name, "jacobi_pair") ? &h->jpair : !strcmp(name, "jacobi_pair_rows") ? &h->jpair_rows : !strcmp(name, "tune_period") ? &h->tune_period : nullptr;
+            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : !strcmp(name, "jacobi_pair") ? &h->jpair : !strcmp(name, "jacobi_pair_rows") ? &h->jpair_rows : !strcmp(name, "pair_vec4") ? &h->pair_vec4 : !strcmp(name, "tune_period") ? &h->tune_period : nullptr;
   if (knob) {
     *knob = (int)value;
     if (knob == &h->band_rows && *knob < 1) *knob = 1;

@@ -15,6 +15,8 @@ rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 api = hip_api()
 kw = {"dt": 1e-6} if n > 4096 else {}
 forms = (("default", {}), ("k_tm + pairs", {"fuse_tm": 1, "jacobi_pair": 2}), ("k_tm, two tb launches", {"fuse_tm": 1, "jacobi_pair": 0}), ("chains / plain", {"fuse_tm": 0}))
+if dtype == "f32":
+    forms += (("k_tm + pairs, 4 per lane", {"fuse_tm": 1, "jacobi_pair": 2, "pair_vec4": 1}), ("k_tm (4 per lane), tb", {"fuse_tm": 1, "jacobi_pair": 0, "pair_vec4": 1}))
 engs = []
 for name, knobs in forms:
     e = Engine(api, make_desc(api, n, n, dtype, "f32", device=0, **kw))
@@ -32,3 +34,10 @@ print("%d^2 %s ic %d, %d rounds of %d steps, ms/step:" % (n, dtype, ic, rounds, 
 for name, e, acc in engs:
     print("  %-24s %s   (tm_choice %d, gas share %.3f, tm_steps %d, pair launches %d, halves_steps %d)" % (
         name, " ".join("%.4f" % x for x in acc), e.get_counter("tm_choice"), e.get_param("gas_share"), e.get_counter("tm_steps"), e.get_counter("pair_launches"), e.get_counter("halves_steps")))
+import hashlib
+def digest(e):
+    h = hashlib.sha256()
+    for f in ("F", "u", "v", "p"):
+        h.update((e.get(f) + 0.0).tobytes())
+    return h.hexdigest()[:12]
+print("  state after %d steps: %s" % (engs[0][1].istep, " ".join(digest(e) for _, e, _ in engs)))

@@ -15,7 +15,7 @@ def remarks(extra=()):
     srcs = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]   # one translation unit (vof2d_api.hip) that includes kernels/ and runtime/
     out = ""
     for s in srcs:
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
                "-fPIC", "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", s, *extra]
         out += subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
     return out
