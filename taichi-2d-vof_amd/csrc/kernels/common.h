@@ -264,7 +264,7 @@ __device__ __forceinline__ float lane_dn_z(float x) { return __int_as_float(dpp_
 // Outside a safe exponent window the remainder r would underflow (tiny a) or q overflow (huge a
 // with |b| < 1).  There the numerator is scaled by an exact power of two, divided the same way and
 // the quotient Q scaled back:
-//   * tiny a (the decaying front of the Jacobi iteration walks through 1e-280 ... 4.9e-324 on its
+//   * tiny a (the decaying front of the Jacobi iteration walks through 1e-289 ... 4.9e-324 on its
 //     way to exact zero): Q * 2^-k is exact while the quotient is normal.  A subnormal quotient is
 //     rounded a second time by that multiplication; the two roundings differ from the single
 //     IEEE one only if Q sits exactly on a midpoint of the subnormal grid (midpoints are
@@ -277,7 +277,10 @@ __device__ __forceinline__ float lane_dn_z(float x) { return __int_as_float(dpp_
 // would cost the register-heavy kernels their allocation).
 template <typename T> struct DivLimits;
 template <> struct DivLimits<double> {
-  static constexpr double lo = 1e-280, hi = 1e280, up = 0x1p+256, dn = 0x1p-256, qmin = 0x1p-766 /* 2^-1022 * up */,
+  // lo: below it the remainder a - b*q of the fast form may fall off the subnormal grid (|a| < 2^-969) or the quotient be subnormal
+  // (|a| < 2^-1022 |b|): 1e-289 = 2^-960 leaves ten binades for |b| up to 2^52.  (1e-280 until round 5: the band of the decaying
+  // front that takes the scaled tier is a fifth narrower.)
+  static constexpr double lo = 1e-289, hi = 1e280, up = 0x1p+256, dn = 0x1p-256, qmin = 0x1p-766 /* 2^-1022 * up */,
                           denorm_min = 0x1p-1074, half_step = 0x1p-819 /* denorm_min * up / 2 */,
                           inf = __builtin_huge_val();
 };

@@ -30,7 +30,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _tiny_cells(p, dtype="f64"):
-    lim = 1e-280 if dtype == "f64" else 1e-25      # DivLimits<T>::lo of the kernels
+    lim = 1e-280 if dtype == "f64" else 1e-25      # (the decaying front: DivLimits<T>::lo of the kernels is 1e-289 / 1e-25)
     q = p[1:-1, 1:-1]
     return int(((np.abs(q) < lim) & (q != 0)).sum())
 
