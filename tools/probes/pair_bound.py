@@ -30,6 +30,8 @@ ap.add_argument("--map", action="store_true")
 ap.add_argument("--tm-rows", default="24,32,40,48,56,64,80,96,128")
 ap.add_argument("--pair-rows", default="40,56,64,72,80,96,120,160")
 ap.add_argument("--no-ablations", action="store_true")
+ap.add_argument("--map-real", action="store_true")
+ap.add_argument("--param", action="append", default=[])
 a = ap.parse_args()
 from vof2d import _abi
 from vof2d.engine import Engine, make_desc
@@ -45,6 +47,8 @@ dbg.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32]
 kw = {"dt": a.dt} if a.dt > 0 else ({"dt": 1e-6} if a.n > 4096 else {})
 e = Engine(api, make_desc(api, a.n, a.n, "f64", "f32", device=0, **kw))
 e.set_param("fuse_tm", 1)
+for kv in a.param:
+    e.set_param(kv.split("=")[0], float(kv.split("=")[1]))
 e.set_init_F(a.ic)
 NAMES = {0: "as shipped", 1: "fixed-row loads", 2: "no store", 3: "fixed-row loads, no store", 4: "wave 0 NOT at prio 1",
          8: "wave 1 at prio 1 too", 16: "wave 1 idle", 32: "wave 0 passes rows on", 48: "wave 0 passes rows on, wave 1 idle",
@@ -122,6 +126,22 @@ for at in [int(x) for x in a.at.split(",")]:
         for which, kid, plan, stride, label in ((1, 14, 0, 112, "k_tm y first"), (0, 13, 0, 108, "k_jacobi_pair (uniform chunks)"), (0, 13, 1, 108, "k_jacobi_pair (work plan)")):
             print(" wave map of one launch of %s:" % label)
             wave_map(which, kid, plan, stride, None)
+    if a.map_real:    # one launch of k_tm as the batch graphs run it (its work plan included): the last k_tm launch of a 16-step batch
+        cap = 1 << 15
+        assert dbg(e._h, 14, None, cap) == 0
+        e.step(16); done += 16
+        e.sync()
+        st = np.zeros((cap, 2), np.uint64)
+        assert dbg(e._h, 14, st.ctypes.data, cap) == 0
+        assert dbg(e._h, -1, None, cap) == 0
+        m = st[:, 1] > 0
+        t0 = st[m, 0].astype(np.int64); t1 = st[m, 1].astype(np.int64)
+        base = t0.min(); dur = (t1 - t0) / 100.0
+        edges = np.linspace(0, t1.max() - base, 21); mid = (edges[:-1] + edges[1:]) / 2 + base
+        print(" k_tm inside the batch graphs (tm_plan_pairs %d): %d waves, span %.1f us, wave us mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f; sum of durations / (span x 3072 slots) = %.2f" % (
+            e.get_counter("tm_plan_pairs"), len(t0), (t1.max() - base) / 100.0, dur.mean(), np.percentile(dur, 10), np.median(dur), np.percentile(dur, 90), dur.max(),
+            dur.sum() / ((t1.max() - base) / 100.0 * 3072)))
+        print("   waves in flight (20 slices): " + " ".join("%d" % int(((t0 <= x) & (t1 > x)).sum()) for x in mid), flush=True)
     if a.rows:
         for knob, which, vals in (("tm_rows", 1, tuple(int(x) for x in a.tm_rows.split(","))), ("jacobi_pair_rows", 0, tuple(int(x) for x in a.pair_rows.split(",")))):
             res = []
