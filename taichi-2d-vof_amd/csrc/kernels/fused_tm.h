@@ -476,7 +476,7 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
                                             T* __restrict__ Uo, T* __restrict__ Vo, T* __restrict__ us_out,
                                             T* __restrict__ vs_out, T* __restrict__ rhs,
                                             unsigned long long* __restrict__ courant, int R, TbPlan tp, int first, int last,
-                                            int first2 = 1, int last2 = 0, TmPlan tq = TmPlan{nullptr, nullptr, 0, 0, 0, 0}) {
+                                            int first2 = 1, int last2 = 0) {
   // rows [first, last] and -- the two edge bands of a strip in one launch -- [first2, last2] (last2 < first2: none), each cut in chunks of R
   constexpr int W = 64 * V, HF = TmGeom::HF, STRIDE = W - 2 * HF;
   static_assert(HF >= 4 + 3 && HF % V == 0, "momentum's inputs must lie inside the transport march's valid columns");
@@ -492,26 +492,16 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
   const int pair = (int)blockIdx.x - plan_blocks;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: transport, 1: momentum
   const int lane = threadIdx.x & 63;
-  int tj = pair % ntf;
-  const int ch = pair / ntf;
+  const int tj = pair % ntf, ch = pair / ntf;
+  const int c0 = 1 - HF + tj * STRIDE;
   int ma = first + ch * R, lim = last;
-  bool planned = false;
-  if (tq.cost != nullptr && tq.plan[0] == (unsigned long long)tq.pairs && tq.pairs > 0) {   // chunks of equal measured cost (tm_make_plan; scalar loads: nobody writes the plan during the launch)
-    const unsigned long long e = tq.plan[1 + pair];
-    tj = __builtin_amdgcn_readfirstlane((int)(e & 0xffull));
-    ma = __builtin_amdgcn_readfirstlane((int)((e >> 8) & 0xfffffffull));
-    lim = __builtin_amdgcn_readfirstlane((int)((e >> 36) & 0xfffffffull));
-    if (lim < ma) return;   // an empty chunk (block-uniform: both waves leave)
-    planned = true;
-  } else if (ma > last) {         // (block-uniform)
+  if (ma > last) {         // (block-uniform)
     const int n1 = last >= first ? (last - first + R) / R : 0;
     ma = first2 + (ch - n1) * R;
     lim = last2;
     if (last2 < first2 || ma > last2) return;   // both waves leave
   }
-  const int c0 = 1 - HF + tj * STRIDE;
-  const int mb = planned ? lim : (ma + R - 1 < lim ? ma + R - 1 : lim);
-  const unsigned long long cyc0 = tq.cost != nullptr ? __builtin_readcyclecounter() : 0ull;
+  const int mb = ma + R - 1 < lim ? ma + R - 1 : lim;
   // interior pair: rows ma - 6 .. mb + 6 in [3, nx - 1], columns c0 - 1 .. c0 + W in [1, ny + 1] with every lane's columns in [2, ny]
   // (on a strip also inside the stored rows: the interior marches do not clamp their row addresses)
   const bool interior = ma >= 9 && mb + 7 <= g.nx && ma - 6 >= g.row_lo && mb + 7 <= g.row_hi && c0 >= 2 && c0 + W - 1 <= g.ny;
@@ -521,11 +511,6 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
   } else {
     if (interior) tm_momentum_march<T, V, BS, true, ABL>(g, c, ring, us_out, vs_out, rhs, c0, lane, ma, mb, wt_);
     else tm_momentum_march<T, V, BS, false, ABL>(g, c, ring, us_out, vs_out, rhs, c0, lane, ma, mb, wt_);
-  }
-  if (tq.cost != nullptr && role == 0 && lane == 0) {   // what a lockstep step of this pair cost, for the bands whose first row it held
-    const float per_step = (float)(__builtin_readcyclecounter() - cyc0) / (float)(mb - ma + 1 + 14);
-    const int bh = tm_band_rows(tq.last - tq.first + 1);
-    for (int b = (ma - tq.first + bh - 1) / bh; tq.first + b * bh <= mb && b < TM_BANDS; ++b) tq.cost[tj * TM_BANDS + b] = per_step;
   }
 }
 

@@ -264,21 +264,14 @@ __device__ __forceinline__ void jacobi_pair_march(const Geom& g, const Consts<T>
 template <typename T, int V, int TS, bool BS, int ABL = 0>
 __global__ __launch_bounds__(128) void k_jacobi_pair(Geom g, Consts<T> c, const T* __restrict__ p,
                                                      const T* __restrict__ rhs, T* __restrict__ pn, int R, int ntt,
-                                                     TbPlan tp, int first, int last, TmPlan tq = TmPlan{nullptr, nullptr, 0, 0, 0, 0}) {
+                                                     TbPlan tp, int first, int last) {
   constexpr int W = 64 * V;
   constexpr int H = ((2 * TS + V - 1) / V) * V;   // TS invalid columns per side and march (TS - 1 cross-lane sweeps + the first sweep's DPP neighbours)
   constexpr int STRIDE = W - 2 * H;
-  static_assert(sizeof(TmPlanShared) <= sizeof(JpRing<float, 2>), "the planner block borrows the rings' LDS");
   __shared__ __attribute__((aligned(16))) JpRing<T, V> lds;
-  // the first block of the launch in front of k_tm plans k_tm's chunks from the durations its pairs measured last step (tm_make_plan)
-  const int plan_blocks = tq.cost != nullptr ? 1 : 0;
-  if (plan_blocks && blockIdx.x == 0) {
-    if (tq.pairs > 0) tm_make_plan(tq, *reinterpret_cast<TmPlanShared*>(&lds));
-    return;
-  }
   WaveTimer wt_(WT_JACOBI_PAIR);
   if (last < first) { first = g.ilo; last = g.ihi; }
-  const int pair = (int)blockIdx.x - plan_blocks;
+  const int pair = (int)blockIdx.x;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   // pair -> (tile column tj, rows [ra, rb]): chunks of R rows of every column, or the equal-cost chunks of the step's plan

@@ -188,158 +188,4 @@ __device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) 
   }
 }
 
-// ------------------------------------------------------------------ work plan of k_tm: chunks of equal MEASURED cost
-// A k_tm launch is two residency rounds of pairs, and a pair's rows cost what they hold: rows of gas go through the
-// transport wave's bypasses, rows of liquid and the interface do not (4096^2 dam-break: 75-100 us for a 52-row chunk of gas,
-// 150 for one of liquid) -- with chunks of equal LENGTH the launch ends with a third of its span half empty (the waves in
-// flight fall off over the last 90 of 300 us; sum of the pairs' durations / slots = 0.75 of the span).  So every pair times
-// itself (s_memtime; cycles per lockstep step), leaves the figure in a table by (row band, tile column), and the next
-// step's planner -- one extra block, the first, of the k_jacobi_pair launch in front of k_tm -- cuts every tile column
-// into chunks of equal cost, as many per column as its share of the total cost asks for: short chunks in the liquid,
-// long ones in the gas, all pairs about equally long.  Which rows a pair takes never changes a value.
-constexpr int TM_BANDS = 128;          // row bands of the cost table
-constexpr int TM_MIN_ROWS = 8;         // shortest planned chunk (a pair's march is its rows + 14 steps)
-struct TmPlan {
-  float* cost;                         // [TB_COLS][TM_BANDS] (column by column): cycles per step of the pair that held the band's first row, last launch; nullptr: no plan
-  unsigned long long* plan;            // [0] = pairs planned (0: the uniform layout), [1 + pair] = plan_pack(tj, ma, mb)
-  int ntf, pairs, first, last;         // tile columns, pairs, rows of the k_tm launch the plan is for
-};
-struct TmPlanShared {
-  float tot[TB_COLS];                  // cost of column j
-  int n[TB_COLS];                      // chunks of column j
-  int S[512];                          // S[k] = pairs in front of the k-th chunks of all columns (chunk-row-major order)
-  int ok, nmin, nmax;
-  float grand;
-};
-__device__ __forceinline__ int tm_band_rows(int rows) { return (rows + TM_BANDS - 1) / TM_BANDS; }
-// One block of 128 threads, thread j = tile column j (ntf <= TB_COLS = 128).  The table is stored column by column
-// (cost[j * TM_BANDS + b]): a thread reads its column sixteen bands at a time with independent 16-byte loads -- a planner
-// that walks the bands with one dependent load each takes longer than the Jacobi launch it rides in.
-struct TmCostReader {
-  const float* col;
-  float v[16];
-  int base;
-  __device__ __forceinline__ void fetch(int b0) {
-    base = b0;
-    const float4* p = reinterpret_cast<const float4*>(col + b0);
-    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
-    v[8] = q2.x; v[9] = q2.y; v[10] = q2.z; v[11] = q2.w; v[12] = q3.x; v[13] = q3.y; v[14] = q3.z; v[15] = q3.w;
-  }
-  __device__ __forceinline__ float at(int b) {   // (b ascends: the window moves with it)
-    if (b >= base + 16) fetch(b & ~15);
-    float r = v[0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) r = (b - base) == k ? v[k] : r;
-    return r;
-  }
-};
-__device__ void tm_make_plan(const TmPlan& tq, TmPlanShared& sh) {
-  const int j = threadIdx.x;
-  const int rows = tq.last - tq.first + 1, bh = tm_band_rows(rows), nb = (rows + bh - 1) / bh;
-  float tot = 0.f;
-  bool ok = true;
-  TmCostReader rd;
-  rd.col = tq.cost + (j < tq.ntf ? j : 0) * TM_BANDS;
-  if (j < tq.ntf) {
-    for (int b0 = 0; b0 < nb; b0 += 16) {
-      rd.fetch(b0);
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int b = b0 + k;
-        if (b < nb) {
-          const float c = rd.v[k];
-          const int rb = (b + 1) * bh <= rows ? bh : rows - b * bh;
-          ok = ok && c > 0.f && c < 1e9f;
-          tot += c * (float)rb;
-        }
-      }
-    }
-    sh.tot[j] = tot;
-  }
-  if (j == 0) { sh.ok = 1; sh.nmin = 1 << 30; sh.nmax = 0; }
-  __syncthreads();
-  if (j < tq.ntf && !ok) sh.ok = 0;
-  __syncthreads();
-  if (j == 0) {
-    float g = 0.f;
-    for (int c = 0; c < tq.ntf; ++c) g += sh.tot[c];
-    sh.grand = g;
-    if (!(g > 0.f) || tq.pairs < tq.ntf || tq.pairs >= 512 * tq.ntf / 2) sh.ok = 0;
-    if (!sh.ok) tq.plan[0] = 0ull;
-  }
-  __syncthreads();
-  if (!sh.ok) return;                  // block-uniform: no table yet (or a broken one): the uniform layout
-  if (j < tq.ntf) {
-    int n = (int)(sh.tot[j] / sh.grand * (float)tq.pairs);
-    const int nmaxj = rows / TM_MIN_ROWS > 1 ? rows / TM_MIN_ROWS : 1;
-    n = n < 1 ? 1 : (n > nmaxj ? nmaxj : n);
-    if (n > 511) n = 511;
-    sh.n[j] = n;
-  }
-  __syncthreads();
-  if (j == 0) {   // the floors leave a few pairs over: one more for the first columns (never more than `pairs`)
-    int sum = 0;
-    for (int c = 0; c < tq.ntf; ++c) sum += sh.n[c];
-    for (int c = 0; c < tq.ntf && sum < tq.pairs; ++c) { if (sh.n[c] < 511) { sh.n[c] += 1; sum += 1; } }
-    for (int c = tq.ntf - 1; sum > tq.pairs && c >= 0; --c) { while (sh.n[c] > 1 && sum > tq.pairs) { sh.n[c] -= 1; sum -= 1; } }
-    int mn = 1 << 30, mx = 0;
-    for (int c = 0; c < tq.ntf; ++c) { mn = sh.n[c] < mn ? sh.n[c] : mn; mx = sh.n[c] > mx ? sh.n[c] : mx; }
-    sh.nmin = mn; sh.nmax = mx;
-  }
-  __syncthreads();
-  for (int k = j; k < 512; k += (int)blockDim.x) {   // pairs with chunk index k, over all columns
-    int cnt = 0;
-    if (k < sh.nmax) for (int c = 0; c < tq.ntf; ++c) cnt += sh.n[c] > k ? 1 : 0;
-    sh.S[k] = cnt;
-  }
-  __syncthreads();
-  if (j == 0) {
-    int run = 0;
-    for (int k = 0; k < 512; ++k) { const int c = sh.S[k]; sh.S[k] = run; run += c; }
-  }
-  __syncthreads();
-  if (j < tq.ntf) {   // one pass over the column's bands: chunk k ends where the cumulative cost reaches (k + 1) / n of the column's
-    const int n = sh.n[j];
-    const float total = sh.tot[j];
-    int b = 0, prev = 0;
-    float cum = 0.f;                  // cost of the bands in front of band b
-    rd.fetch(0);
-    for (int k = 0; k < n; ++k) {
-      int pos = rows;
-      if (k < n - 1) {
-        const float x = total * (float)(k + 1) / (float)n;
-        for (;;) {
-          const float c = rd.at(b);
-          const int rb = (b + 1) * bh <= rows ? bh : rows - b * bh;
-          if (b >= nb - 1 || cum + c * (float)rb > x) {
-            int in = (int)((x - cum) / c);
-            in = in < 0 ? 0 : (in > rb ? rb : in);
-            pos = b * bh + in;
-            break;
-          }
-          cum += c * (float)rb;
-          ++b;
-        }
-        if (pos < prev + TM_MIN_ROWS) pos = prev + TM_MIN_ROWS;
-        if (pos > rows) pos = rows;
-      }
-      // position of (j, k) in the launch: chunk-row-major, so that the rows in flight stay one band of the grid
-      int idx = sh.S[k];
-      if (k < sh.nmin) idx += j;
-      else for (int c = 0; c < j; ++c) idx += sh.n[c] > k ? 1 : 0;
-      tq.plan[1 + idx] = plan_pack(j, tq.first + prev, tq.first + pos - 1);   // (pos == prev: an empty chunk, the pair leaves at once)
-      prev = pos;
-    }
-  }
-  __syncthreads();
-  if (j == 0) {
-    int sum = 0;
-    for (int c = 0; c < tq.ntf; ++c) sum += sh.n[c];
-    for (int w = sum; w < tq.pairs; ++w) tq.plan[1 + w] = plan_pack(0, 1, 0);   // (pairs past the planned ones: empty)
-    __threadfence();
-    tq.plan[0] = (unsigned long long)tq.pairs;
-  }
-}
-
 }  // namespace vof

@@ -150,8 +150,6 @@ struct vof2d_ctx {
   int tb_adapt = 1;     // fused steps: shorter chunks on the tile columns the tiny-value front is crossing (k_jacobi_tb)
   unsigned long long* d_tbmask = nullptr;  // work plan of k_jacobi_tb (TbPlan): 2 x TB_BANDS mask words, then the plan (1 + waves entries)
   long tbplan_cap = 0;                     // waves the plan area holds
-  unsigned long long* d_tmplan = nullptr;  // work plan of k_tm (TmPlan): [0] pairs planned, kTmPlanPairs entries, then the cost table (TM_BANDS x TB_COLS floats)
-  int tm_plan = 1;                         // knob "tm_plan": k_tm's pairs time themselves and the next step's chunks are cut by measured cost
   int fctx_rows = 0;    // rows per wave chunk of k_fct_x (0 = heuristic, at most 16)
   int fctx_corr_rows = 0;  // ... of its update_uv-carrying form (0 = same rule)
   int fuse_transport = 1;  // vof_step on a full domain: update_uv and both FCT sweeps in one kernel (k_transport)

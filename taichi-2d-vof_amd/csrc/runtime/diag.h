@@ -16,7 +16,7 @@ void dbg_pair(vof2d_ctx* h, int plan) {
   h->jpair_active = false;
   const unsigned pairs = tp.masks ? (unsigned)tp.waves : (unsigned)(((h->g.ihi - h->g.ilo + R) / R) * ntt);
   launch_block(h, kJacobiPair, k_jacobi_pair<T, V, 5, true, ABL>, dim3(pairs), 128u, 0, h->g, L<T>::C(h), (const T*)F_<T>(h, fP),
-               (const T*)F_<T>(h, fRHS), F_<T>(h, fPT), R, ntt, tp, h->g.ilo, h->g.ihi, TmPlan{nullptr, nullptr, 0, 0, 0, 0});
+               (const T*)F_<T>(h, fRHS), F_<T>(h, fPT), R, ntt, tp, h->g.ilo, h->g.ihi);
 }
 template <bool YFIRST, int ABL>
 void dbg_tm(vof2d_ctx* h) {
@@ -28,7 +28,7 @@ void dbg_tm(vof2d_ctx* h) {
   const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf);
   launch_block(h, kTM, k_tm<T, V, YFIRST, false, true, ABL>, dim3(pairs), 128u, 0, h->g, L<T>::C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
                (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
-               F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant + 3, R, tp, first, last, 1, 0, TmPlan{nullptr, nullptr, 0, 0, 0, 0});
+               F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant + 3, R, tp, first, last, 1, 0);
 }
 
 }  // namespace

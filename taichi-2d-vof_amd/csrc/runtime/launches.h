@@ -120,8 +120,6 @@ inline bool buffer_stores_ok(const vof2d_ctx* h) {
 
 // ------------------------------------------------------------------ launches
 constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe
-constexpr long kTmPlanPairs = 16384;   // pairs of a k_tm launch its work plan can describe
-inline size_t tmplan_bytes() { return (2 + kTmPlanPairs) * sizeof(unsigned long long) + (size_t)TM_BANDS * TB_COLS * sizeof(float); }   // (the table 16-byte aligned)
 enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
                 kRhs, kOther, kTransport, kJacobiPair, kTM, NKERNELS };
 const char* const kKernelNames[NKERNELS] = {"k_momentum", "k_set_bc", "k_jacobi", "k_jacobi_tb", "k_correct",
@@ -284,17 +282,14 @@ struct L {
     int ntt = 0;
     const int R = jacobi_pair_geom_v<VV>(h, ntt);
     const TbPlan tp = tb_plan(h, adapt_par);
-    // (inside the k_tm batch graphs: the planner of k_tm's chunks rides in this launch, its first block)
-    TmPlan tq = (h->jpair_active && first == h->g.ilo && last == h->g.ihi) ? tm_plan_args(h) : TmPlan{nullptr, nullptr, 0, 0, 0, 0};
-    if (h->tm_plan == 2) tq.pairs = 0;   // (experiment: the extra block without the planning)
-    const unsigned pairs = (tp.masks ? (unsigned)tp.waves : (unsigned)(((last - first + R) / R) * ntt)) + (tq.cost ? 1u : 0u);
+    const unsigned pairs = tp.masks ? (unsigned)tp.waves : (unsigned)(((last - first + R) / R) * ntt);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 2);
     if (bs)
       launch_block(h, kJacobiPair, k_jacobi_pair<T, VV, 5, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
-                   (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last, tq);
+                   (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last);
     else
       launch_block(h, kJacobiPair, k_jacobi_pair<T, VV, 5, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, src),
-                   (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last, tq);
+                   (const T*)F_<T>(h, fRHS), F_<T>(h, dst), R, ntt, tp, first, last);
   }
   static void jacobi_pair(vof2d_ctx* h, int src, int dst, int adapt_par = -1, int first = 1, int last = 0) {
     if (last < first) { first = h->g.ilo; last = h->g.ihi; }
@@ -420,26 +415,6 @@ struct L {
   // k_transport of this step + k_momentum of the next in one launch (k_tm): reads fld[fF], fld[fUS], fld[fVS], fld[fP];
   // writes fld[fF2], rhs, u*' / v*' into fld[fMX] / fld[fMY] (the caller alternates the pairs and swaps F), u and v
   // only with STORE_UV; adapt_par: parity of the NEXT step (its planner block rides here as it does in k_momentum)
-  // k_tm's self-timed work plan (tm_make_plan): full domains whose Jacobi sweeps are k_jacobi_pair launches (the planner rides
-  // in the launch in front of k_tm), both launches given the same geometry
-  static TmPlan tm_plan_args(vof2d_ctx* h) {
-    TmPlan tq{nullptr, nullptr, 0, 0, 0, 0};
-    if (!h->tm_plan || !h->d_tmplan || !(h->g.wall_lo && h->g.wall_hi) || !jacobi_pair_ok(h) || h->tm_rows > 0) return tq;
-    constexpr int ST = 64 * V - 2 * TmGeom::HF;
-    const int ntf = (h->g.ny + ST - 1) / ST, first = h->g.ilo, last = h->g.ihi;
-    const long cap = resident_blocks(h, k_tm<T, V, true, false, true>, 128);
-    const int R = tm_chunk_rows(h, last - first + 1, ntf, cap);
-    // (equal-cost pairs end together: whole residency rounds, 98 % filled -- the uniform layout's count rounded to rounds)
-    const long uni = (long)((last - first + R) / R) * ntf;
-    long k = (uni + cap / 2) / cap;
-    if (k < 1) k = 1;
-    const long pairs = k * cap * 98 / 100;
-    if (ntf > TB_COLS || pairs > kTmPlanPairs || pairs < 2L * ntf) return tq;
-    tq.plan = h->d_tmplan;
-    tq.cost = reinterpret_cast<float*>(h->d_tmplan + 2 + kTmPlanPairs);
-    tq.ntf = ntf; tq.pairs = (int)pairs; tq.first = first; tq.last = last;
-    return tq;
-  }
   static int tm_chunk_rows(const vof2d_ctx* h, long rows, int ntf, long cap) {
     if (h->tm_rows > 0) return h->tm_rows;
     long k = (rows * ntf + cap * 25) / (cap * 50);
@@ -468,22 +443,16 @@ struct L {
     // 100 376 / 381 (tools/probes/pair_bound.py --rows)
     const int R = rows_forced > 0 ? rows_forced : tm_chunk_rows(h, last - first + 1, ntf, resident_blocks(h, k_tm<T, VV, YFIRST, STORE_UV, true>, 128));
     const TbPlan tp = tb_plan(h, adapt_par);
-    TmPlan tq{nullptr, nullptr, 0, 0, 0, 0};
-    if (VV == V && rows_forced <= 0 && last2 < first2 && first == h->g.ilo && last == h->g.ihi) tq = tm_plan_args(h);
-    // (a planned launch holds the plan's pairs; while there is no plan yet, the uniform layout's pairs do the work and the rest leave at once)
-    unsigned pairs = (unsigned)((((last - first + R) / R) + (last2 >= first2 ? (last2 - first2 + R) / R : 0)) * ntf);
-    if (tq.cost && (unsigned)tq.pairs > pairs) pairs = (unsigned)tq.pairs;
-    if (tq.cost && (unsigned)tq.pairs < pairs) tq = TmPlan{nullptr, nullptr, 0, 0, 0, 0};   // (never: whole rounds of the same geometry)
-    pairs += tp.masks ? 1u : 0u;
+    const unsigned pairs = (unsigned)((((last - first + R) / R) + (last2 >= first2 ? (last2 - first2 + R) / R : 0)) * ntf) + (tp.masks ? 1u : 0u);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 4);
     if (bs)
       launch_block(h, kTM, k_tm<T, VV, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
-             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2, tq);
+             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2);
     else
       launch_block(h, kTM, k_tm<T, VV, YFIRST, STORE_UV, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
-             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2, tq);
+             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2);
   }
   // update_uv + both sweeps + post_process_f in one pass (k_transport); reads fld[fF], writes fld[fF2]
   static int transport_rows(const vof2d_ctx* h) {

@@ -104,8 +104,6 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
     if (hipMemsetAsync(h->d_courant, 0, 4 * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipMalloc(reinterpret_cast<void**>(&h->d_tbmask), (2 * TB_BANDS * (TB_COLS / 64) + 1 + kTbPlanWaves) * sizeof(unsigned long long)) != hipSuccess) { rc = VOF_ENOMEM; break; }
     if (hipMemsetAsync(h->d_tbmask, 0, (2 * TB_BANDS * (TB_COLS / 64) + 1 + kTbPlanWaves) * sizeof(unsigned long long), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
-    if (hipMalloc(reinterpret_cast<void**>(&h->d_tmplan), tmplan_bytes()) != hipSuccess) { rc = VOF_ENOMEM; break; }
-    if (hipMemsetAsync(h->d_tmplan, 0, tmplan_bytes(), h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = VOF_EHIP; break; }
     if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = VOF_EHIP; break; }
   } while (0);
@@ -142,7 +140,6 @@ int vof_destroy(vof2d_handle h) {
 #endif
   if (h->d_courant) (void)hipFree(h->d_courant);
   if (h->d_tbmask) (void)hipFree(h->d_tbmask);
-  if (h->d_tmplan) (void)hipFree(h->d_tmplan);
   if (h->arena) (void)hipFree(h->arena);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -708,14 +705,13 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
             : !strcmp(name, "momentum_rows") ? &h->mom_rows : !strcmp(name, "fctx_rows") ? &h->fctx_rows
             : !strcmp(name, "fctx_corr_rows") ? &h->fctx_corr_rows : !strcmp(name, "band_rows") ? &h->band_rows
             : !strcmp(name, "rows_per_wave") ? &h->rows_override : !strcmp(name, "fuse_transport") ? &h->fuse_transport
-            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : !strcmp(name, "jacobi_pair") ? &h->jpair : !strcmp(name, "jacobi_pair_rows") ? &h->jpair_rows : !strcmp(name, "pair_vec4") ? &h->pair_vec4 : !strcmp(name, "tm_plan") ? &h->tm_plan : !strcmp(name, "tune_period") ? &h->tune_period : nullptr;
+            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : !strcmp(name, "jacobi_pair") ? &h->jpair : !strcmp(name, "jacobi_pair_rows") ? &h->jpair_rows : !strcmp(name, "pair_vec4") ? &h->pair_vec4 : !strcmp(name, "tune_period") ? &h->tune_period : nullptr;
   if (knob) {
     *knob = (int)value;
     if (knob == &h->band_rows && *knob < 1) *knob = 1;
     if (knob == &h->step_batch[0]) *knob = *knob < 4 ? 4 : (*knob & ~1);   // an even number of steps (see vof_step)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     destroy_graphs(h);
-    if (h->d_tmplan) (void)hipMemsetAsync(h->d_tmplan, 0, tmplan_bytes(), h->stream);   // (k_tm's plan and cost table belong to the old geometry)
     return VOF_OK;
   }
   return fail(h, VOF_EINVAL, "unknown or read-only parameter");
@@ -753,13 +749,6 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
   if (!strcmp(name, "tb_plan_active")) {   // 1 if the last fused step's k_jacobi_tb launches ran the equal-cost work plan (tb_make_plan)
     unsigned long long v = 0;
     HIPCHK(h, hipMemcpyAsync(&v, h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64), sizeof(v), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    *value = (int64_t)v;
-    return VOF_OK;
-  }
-  if (!strcmp(name, "tm_plan_pairs")) {   // pairs of the last k_tm work plan (0: the uniform layout ran / will run)
-    unsigned long long v = 0;
-    HIPCHK(h, hipMemcpyAsync(&v, h->d_tmplan, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *value = (int64_t)v;
     return VOF_OK;

@@ -139,7 +139,7 @@ for at in [int(x) for x in a.at.split(",")]:
         base = t0.min(); dur = (t1 - t0) / 100.0
         edges = np.linspace(0, t1.max() - base, 21); mid = (edges[:-1] + edges[1:]) / 2 + base
         print(" k_tm inside the batch graphs (tm_plan_pairs %d): %d waves, span %.1f us, wave us mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f; sum of durations / (span x 3072 slots) = %.2f" % (
-            e.get_counter("tm_plan_pairs"), len(t0), (t1.max() - base) / 100.0, dur.mean(), np.percentile(dur, 10), np.median(dur), np.percentile(dur, 90), dur.max(),
+            0, len(t0), (t1.max() - base) / 100.0, dur.mean(), np.percentile(dur, 10), np.median(dur), np.percentile(dur, 90), dur.max(),
             dur.sum() / ((t1.max() - base) / 100.0 * 3072)))
         print("   waves in flight (20 slices): " + " ".join("%d" % int(((t0 <= x) & (t1 > x)).sum()) for x in mid), flush=True)
     if a.rows:
