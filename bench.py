@@ -34,7 +34,8 @@ ARRAYS_PER_STEP_STRIP = 22
 # algorithmic array passes per launch of the kernels of the fused step (same counting rule)
 KERNEL_PASSES = {"k_momentum": 6, "k_jacobi_tb": 3, "k_transport": 7, "k_jacobi": 3, "k_fct_x": 7, "k_fct_y": 7,
                  # k_tm (k_transport + the next step's k_momentum): F, u*, v*, p -> F'', u*', v*', rhs'; k_jacobi_pair: p, rhs -> p after TEN sweeps
-                 "k_tm": 8, "k_jacobi_pair": 3}
+                 # k_tm_uv: the last k_tm of a batch, which also stores u and v (the batches chain: no plain k_momentum / k_transport is left)
+                 "k_tm": 8, "k_tm_uv": 10, "k_jacobi_pair": 3}
 
 
 def parse():
@@ -791,8 +792,9 @@ def main():
         ARRAYS_PER_STEP = 11        # k_jacobi_pair 3 + k_tm 8 per middle step (the head and the tail of a call: once per call)
     # What the step AS THE HANDLE RAN IT has to move, by SURVEY 8d's rule applied to its own kernel list (every distinct
     # array a kernel reads or writes, once, times its launches per step, from the in-situ profile of the kept form):
-    # 8 x 0.875 (k_tm) + 3 (k_jacobi_pair: ten sweeps) + 13 x 0.125 (the plain k_momentum / k_transport at the ends of a
-    # 16-step batch) = 11.6 passes where the pair kernels run, 6 + 2 x 3 + 7 = 19 for the four-kernel schedule.  Three
+    # 8 x 15/16 (k_tm) + 10 x 1/16 (the last k_tm of a 16-step batch, which also stores u and v: the batches chain, no plain
+    # k_momentum / k_transport is left) + 3 (k_jacobi_pair: ten sweeps) = 11.1 passes where the pair kernels run,
+    # 6 + 2 x 3 + 7 = 19 for the four-kernel schedule.  Three
     # step fractions stand side by side in `config`: on this list, on the 19 passes of the four-kernel schedule every
     # earlier round quoted, and on the HBM traffic the counters saw.
     own_kernels = run_kernels if "k_tm" in run_kernels else step_kernels
@@ -801,7 +803,7 @@ def main():
     traffic_all, traffic_all_note = ({}, "N > 1")
     if not dist_path:
         traffic_all, traffic_all_note = load_pmc_traffic(nx, ny, a.dtype, os.path.join(ROOT, "profiles", "tm_pmc.json" if "k_tm" in run_kernels else "jacobi_pmc.json"))
-    fam = {"k_tm": "tm", "k_jacobi_pair": "pair", "k_jacobi_tb": "tb", "k_momentum": "momentum", "k_transport": "transport", "k_jacobi": "single"}
+    fam = {"k_tm": "tm", "k_tm_uv": "tm_uv", "k_jacobi_pair": "pair", "k_jacobi_tb": "tb", "k_momentum": "momentum", "k_transport": "transport", "k_jacobi": "single"}
     step_traffic = None
     if own_kernels and all(fam.get(k) in traffic_all for k in own_kernels):
         step_traffic = sum(v["launches_per_step"] * traffic_all[fam[k]] for k, v in own_kernels.items())

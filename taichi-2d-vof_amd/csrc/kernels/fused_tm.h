@@ -209,7 +209,12 @@ __device__ __forceinline__ void tm_transport_march(const Geom& g, const Consts<T
         }
         ring_put<T, V>(ring.u[r & 7], lane, ur);
         ring_put<T, V>(ring.v[r & 7], lane, vr);
-        if (STORE_UV && own && !(ABL & ABL_NO_STORE)) {
+        if constexpr (STORE_UV && BS && IN && !(ABL & ABL_NO_STORE)) {
+          // (an interior pair: no wall row, no wall column -- u and v leave like F'', range-checked buffer stores)
+          const int so = own ? (int)((int64_t)(r - g.row_lo) * pitch * (int64_t)sizeof(T)) : 0;
+          store_buf_nt<T, V>(Uo + (int64_t)(g.col0 + c0), own ? voff_st : kBufSkip, so, ur);
+          store_buf_nt<T, V>(Vo + (int64_t)(g.col0 + c0), own ? voff_st : kBufSkip, so, vr);
+        } else if (STORE_UV && own && !(ABL & ABL_NO_STORE)) {
           store_s<T, V>(Uo + at(g, r, j0), ur, j0, jlo, jhi);
           store_s<T, V>(Vo + at(g, r, j0), vr, j0, jlo, jhi == ny ? ny + 1 : jhi);
           if (r == nx) {

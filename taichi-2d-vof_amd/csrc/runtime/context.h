@@ -180,6 +180,9 @@ struct vof2d_ctx {
   int fuse_tm = -1;
   double gas_share = -1.0;   // what the rule saw (get_param "gas_share")
   bool tm_broken = false;    // the k_tm batch graphs could not be captured: the other form stays
+  bool ahead = false;        // u*, v*, rhs hold the predictor of step istep + 1 (the chained k_tm batches; settle_ahead)
+  bool tm_rhs_alt = false;   // the k_tm launches being enqueued write rhs into the kappa array (the caller swaps the views)
+  int64_t tm_chained = 0;    // k_tm batches that started without a k_momentum launch (counter "tm_chained_batches")
   int jpair = 1;             // knob "jacobi_pair": the k_tm batch graphs run each two five-sweep launches as one k_jacobi_pair launch
   int jpair_rows = 0;        // rows per pair chunk (0 = one residency round of pairs)
   int pair_vec4 = 0;         // knob "pair_vec4": fp32 pair kernels with four columns per lane (256-column tiles)

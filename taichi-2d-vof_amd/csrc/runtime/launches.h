@@ -121,10 +121,10 @@ inline bool buffer_stores_ok(const vof2d_ctx* h) {
 // ------------------------------------------------------------------ launches
 constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe
 enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
-                kRhs, kOther, kTransport, kJacobiPair, kTM, NKERNELS };
+                kRhs, kOther, kTransport, kJacobiPair, kTM, kTMUV, NKERNELS };
 const char* const kKernelNames[NKERNELS] = {"k_momentum", "k_set_bc", "k_jacobi", "k_jacobi_tb", "k_correct",
                                             "k_fct_x", "k_fct_y", "k_normals", "k_kappa", "k_predictor", "k_rhs",
-                                            "other", "k_transport", "k_jacobi_pair", "k_tm"};
+                                            "other", "k_transport", "k_jacobi_pair", "k_tm", "k_tm_uv"};   // (k_tm_uv: the k_tm launch that also stores u, v -- the last of a batch)
 
 // One place through which every kernel is launched.  In profiling mode the dispatch carries its
 // own start/stop events (hipExtLaunchKernelGGL: the begin/end timestamps of the dispatch itself,
@@ -446,13 +446,13 @@ struct L {
     const unsigned pairs = (unsigned)((((last - first + R) / R) + (last2 >= first2 ? (last2 - first2 + R) / R : 0)) * ntf) + (tp.masks ? 1u : 0u);
     const bool bs = buffer_stores_ok(h) && (h->buf_stores & 4);
     if (bs)
-      launch_block(h, kTM, k_tm<T, VV, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+      launch_block(h, STORE_UV ? kTMUV : kTM, k_tm<T, VV, YFIRST, STORE_UV, true>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
-             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2);
+             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, h->tm_rhs_alt ? fKAPPA : fRHS), h->d_courant, R, tp, first, last, first2, last2);
     else
-      launch_block(h, kTM, k_tm<T, VV, YFIRST, STORE_UV, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
+      launch_block(h, STORE_UV ? kTMUV : kTM, k_tm<T, VV, YFIRST, STORE_UV, false>, dim3(pairs), 128u, 0, h->g, C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
              (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),
-             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, fRHS), h->d_courant, R, tp, first, last, first2, last2);
+             F_<T>(h, fMX), F_<T>(h, fMY), F_<T>(h, h->tm_rhs_alt ? fKAPPA : fRHS), h->d_courant, R, tp, first, last, first2, last2);
   }
   // update_uv + both sweeps + post_process_f in one pass (k_transport); reads fld[fF], writes fld[fF2]
   static int transport_rows(const vof2d_ctx* h) {

@@ -192,6 +192,12 @@ inline void swap_S(vof2d_ctx* h) {
   void* t = h->fld[fUS]; h->fld[fUS] = h->fld[fMX]; h->fld[fMX] = t;
   t = h->fld[fVS]; h->fld[fVS] = h->fld[fMY]; h->fld[fMY] = t;
 }
+// ... and rhs with the (otherwise verb-only) kappa array: the chained k_tm batches, whose every launch leaves the
+// previous step's u*, v*, rhs intact beside the next step's (enqueue_steps_tm)
+inline void swap_SR(vof2d_ctx* h) {
+  swap_S(h);
+  void* t = h->fld[fRHS]; h->fld[fRHS] = h->fld[fKAPPA]; h->fld[fKAPPA] = t;
+}
 inline bool tm_eligible(const vof2d_ctx* h) {
   return h->fuse_tm != 0 && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 && h->d.jacobi_iters % 5 == 0 &&
          h->d.jacobi_iters / 5 % 2 == 0 && h->g.nx >= 16;
@@ -297,10 +303,14 @@ bool enqueue_steps_halves(vof2d_ctx* h, int64_t first_step, int K) {
   return ok;
 }
 
-// K steady-state steps of a full domain with the step boundary fused away: k_momentum, then per step two Jacobi
-// launches and k_tm (this step's transport + the next step's momentum), the last step ending in a plain k_transport
-// that stores u and v.  u*, v* alternate between their own arrays and the (otherwise verb-only) mx, my arrays; the
-// first k_momentum writes whichever pair makes the last step's land in their own.
+// K steady-state steps of a full domain with the step boundary fused away, and the batch boundary too: the handle is
+// AHEAD when this runs -- u*, v*, rhs hold the predictor of the batch's first step (the last k_tm of the batch before, or
+// one k_momentum launch in front of the first batch: vof_step) -- so a batch is K x (the step's Jacobi launches, k_tm =
+// this step's transport + the next step's momentum), the last k_tm also storing u and v (nothing inside a batch reads
+// them from memory; everything outside does).  Every k_tm writes the next predictor into the OTHER set of (u*, v*, rhs)
+// arrays -- (mx, my, kappa), verb-only otherwise -- and the host's view of the sets alternates: after an even number of
+// steps the view is where it was, holding step K + 1's predictor, and the other set still holds step K's -- what the
+// reference's u_star, v_star, rhs hold after K steps (settle_ahead copies it over when somebody asks).
 inline void swap_P(vof2d_ctx* h) { void* t = h->fld[fP]; h->fld[fP] = h->fld[fPT]; h->fld[fPT] = t; }
 // the step's Jacobi sweeps inside a batch: pairs of five-sweep launches as k_jacobi_pair where the handle allows (each
 // leaves its result in the other array of the p / pt pair: the host's view is swapped along, an even number of times
@@ -325,23 +335,34 @@ template <typename T>
 void enqueue_steps_tm(vof2d_ctx* h, int64_t first_step, int K) {
   h->jpair_active = L<T>::jacobi_pair_ok(h);
   h->jpair_captured = h->jpair_active;
-  if ((K - 1) & 1) swap_S(h);
-  L<T>::momentum(h, true, (int)(first_step & 1));
+  h->tm_rhs_alt = true;
   for (int k = 0; k < K; ++k) {
     const int64_t istep = first_step + k;
     const int par = (int)(istep & 1);
     batch_jacobi<T>(h, par);
     if (k < K - 1) {
       if (istep % 2 == 0) L<T>::template tm<true, false>(h, par ^ 1); else L<T>::template tm<false, false>(h, par ^ 1);
-      swap_S(h);
     } else {
-      if (istep % 2 == 0) L<T>::template transport<true>(h); else L<T>::template transport<false>(h);
+      if (istep % 2 == 0) L<T>::template tm<true, true>(h, par ^ 1); else L<T>::template tm<false, true>(h, par ^ 1);
     }
+    swap_SR(h);
     swap_F(h);
   }
+  h->tm_rhs_alt = false;
   if (h->jpair_active && ((K * (h->d.jacobi_iters / 10)) & 1)) swap_P(h);   // (never: K is even)
   h->jpair_active = false;
-  // (the first swap and the K - 1 in the loop are an even number: the host's view of the pairs is back where it was)
+  // (K swaps, an even number: the host's view of the pairs is back where it was)
+}
+// The handle leaves the chained k_tm batches (a field is read or written from outside, a verb, a parameter): the
+// reference's u_star, v_star, rhs after the last step are in the other set of arrays -- copy them into the host's view.
+int settle_ahead(vof2d_ctx* h) {
+  if (!h->ahead) return VOF_OK;
+  h->ahead = false;
+  const size_t bytes = h->field_elems * h->esz;
+  HIPCHK(h, hipMemcpyAsync(h->fld[fUS], h->fld[fMX], bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->fld[fVS], h->fld[fMY], bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->fld[fRHS], h->fld[fKAPPA], bytes, hipMemcpyDeviceToDevice, h->stream));
+  return VOF_OK;
 }
 
 int ensure_ok(vof2d_ctx* h) {
@@ -366,6 +387,7 @@ bool step_leaves_ghosts_virtual(const vof2d_ctx* h) {
 // Every entry point that reads or writes fields other than through the fused step calls this
 // first: if the last step skipped its set_BC launch, run it now (u, v, F with its twin, p).
 void settle_ghosts(vof2d_ctx* h) {
+  (void)settle_ahead(h);
   if (!h->ghosts_virtual) return;
   DISPATCH_T(h, L<double>::set_bc<BC_ALL>(h), L<float>::set_bc<BC_ALL>(h));
   h->ghosts_virtual = false;

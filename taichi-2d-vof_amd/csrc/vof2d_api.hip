@@ -247,6 +247,11 @@ int vof_post_process_f(vof2d_handle h) {
 // was moved alone (vof_set_istep) gets the other two on its next steady-state step.  Captures enqueue nothing.  Any
 // failure on the way ends the capture, puts the F / twin pair back, switches batching off for the handle and leaves
 // the single-step graphs (or eager launches) to carry on: never an error of vof_step.
+// steps per graph launch of batch size b: the chained k_tm batches pay one u, v store per batch and nothing else, so
+// their largest is twice the other form's (whose chains drift kHalvesDrift rows per launch: halves_prepare)
+static int batch_steps(const vof2d_ctx* h, int variant, int b) {
+  return (variant && b == 0) ? 2 * h->step_batch[0] : h->step_batch[b];
+}
 static void build_step_batches(vof2d_ctx* h, int variant /* 0: chains or the plain sequence, 1: k_tm */) {
   auto& GB = variant ? h->gbatch_tm : h->gbatch;
   void* const f0 = h->fld[fF];
@@ -268,7 +273,7 @@ static void build_step_batches(vof2d_ctx* h, int variant /* 0: chains or the pla
         h->halves_captured[b] = true;
         DISPATCH_T(h, enq = enqueue_steps_halves<double>(h, first, h->step_batch[b]), enq = enqueue_steps_halves<float>(h, first, h->step_batch[b]));
       } else if (fused_tm) {
-        DISPATCH_T(h, enqueue_steps_tm<double>(h, first, h->step_batch[b]), enqueue_steps_tm<float>(h, first, h->step_batch[b]));
+        DISPATCH_T(h, enqueue_steps_tm<double>(h, first, batch_steps(h, 1, b)), enqueue_steps_tm<float>(h, first, batch_steps(h, 1, b)));
       } else
         for (int k = 0; k < h->step_batch[b]; ++k)
           DISPATCH_T(h, enqueue_step<double>(h, first + k, true, true), enqueue_step<float>(h, first + k, true, true));
@@ -383,7 +388,7 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       const int ori = h->fld[fF] == h->f_home ? 0 : 1;
       bool batched = false;
       for (int b = timed ? vof2d_ctx::kTuneBatch : 0; b < vof2d_ctx::kStepBatches && !batched; ++b) {   // (while the forms are being timed: batches of the timed size)
-        const int K = h->step_batch[b];
+        const int K = batch_steps(h, variant, b);
         if (nsteps - s < K || !GB[b][par][ori]) continue;
         const bool time_it = timed && b == vof2d_ctx::kTuneBatch && h->batching;
         if (time_it) {
@@ -391,6 +396,13 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
             if (!h->tune_ev[2 * h->tune_n + k] && hipEventCreate(&h->tune_ev[2 * h->tune_n + k]) != hipSuccess) { h->istep -= 1; return fail(h, VOF_EHIP, "hipEventCreate"); }
           if (hipEventRecord(h->tune_ev[2 * h->tune_n], h->stream) != hipSuccess) { h->istep -= 1; return fail(h, VOF_EHIP, "hipEventRecord"); }
         }
+        if (variant) {
+          // the k_tm batches chain: each ends with the next step's predictor in place (enqueue_steps_tm); only the first
+          // after anything else needs its k_momentum launched in front
+          if (h->ahead) h->tm_chained += 1;
+          else DISPATCH_T(h, L<double>::momentum(h, true, par), L<float>::momentum(h, true, par));
+          h->ahead = true;
+        } else h->ahead = false;
         if (hipGraphLaunch(GB[b][par][ori], h->stream) != hipSuccess) { h->istep -= 1; return fail(h, VOF_EHIP, "hipGraphLaunch of a step batch"); }
         if (time_it) {
           if (hipEventRecord(h->tune_ev[2 * h->tune_n + 1], h->stream) == hipSuccess) h->tune_n += 1;
@@ -407,6 +419,7 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
         continue;
       }
     }
+    h->ahead = false;   // (this step forms its own predictor, into the host's view of u*, v*, rhs)
     if (use_graph && lean && regular) {
       // graphs bake the field pointers in: one per (parity, which buffer of the F / twin pair holds
       // F).  The two-kernel transport swaps the pair twice per step, the fused one once.
@@ -690,6 +703,7 @@ int vof_interp_velocity(vof2d_handle h, void* dst, size_t nbytes) {
 int vof_set_param(vof2d_handle h, const char* name, double value) {
   if (!h || !name) return VOF_EINVAL;
   if (!strcmp(name, "sigma")) {  // sigma[None] = value (2dvof.py:28-29); constants are baked into graphs
+    (void)settle_ahead(h);   // (a predictor formed ahead of its step used the old value)
     h->d.sigma = value;
     h->cd.sigma = value;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -757,6 +771,10 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
     *value = h->pair_launches;
     return VOF_OK;
   }
+  if (!strcmp(name, "tm_chained_batches")) {   // k_tm batches that found the predictor of their first step in place
+    *value = h->tm_chained;
+    return VOF_OK;
+  }
   if (!strcmp(name, "tm_steps")) {   // steps replayed from batch graphs in the k_tm form
     *value = h->tm_steps;
     return VOF_OK;
@@ -814,8 +832,12 @@ int vof_profile_steps(vof2d_handle h, int64_t nsteps) {
     if (tm_form) {
       // (1 + K x (Jacobi launches + 1) launches, each with its own event pair out of the pool)
       const int per_tm_step = 1 + (DISPATCH_B(h, L<double>::jacobi_pair_ok(h), L<float>::jacobi_pair_ok(h)) ? h->d.jacobi_iters / 10 : h->d.jacobi_iters / 5);
-      const int K = (nsteps - done >= 8 && 1 + 8 * per_tm_step <= vof2d_ctx::kMaxTimed) ? 8 : 2;
+      int K = 2;   // the handle's own batch sizes (an even number of steps each), as far as the event pool allows
+      for (int b = vof2d_ctx::kStepBatches - 1; b >= 0; --b)
+        if (nsteps - done >= batch_steps(h, 1, b) && 1 + batch_steps(h, 1, b) * per_tm_step <= vof2d_ctx::kMaxTimed && batch_steps(h, 1, b) > K) K = batch_steps(h, 1, b);
       if (1 + K * per_tm_step > vof2d_ctx::kMaxTimed) { h->timed = -1; return fail(h, VOF_ESTATE, "a k_tm batch of two steps has more launches than the profiling event pool"); }
+      if (!h->ahead) DISPATCH_T(h, L<double>::momentum(h, true, (int)((h->istep + 1) & 1)), L<float>::momentum(h, true, (int)((h->istep + 1) & 1)));
+      h->ahead = true;
       DISPATCH_T(h, enqueue_steps_tm<double>(h, h->istep + 1, K), enqueue_steps_tm<float>(h, h->istep + 1, K));
       h->istep += K;
       h->ghosts_virtual = true;
@@ -823,6 +845,7 @@ int vof_profile_steps(vof2d_handle h, int64_t nsteps) {
     }
     while (!tm_form && done + batch < nsteps && h->timed + per_step <= vof2d_ctx::kMaxTimed) {
       h->istep += 1;
+      h->ahead = false;
       const bool lean = !h->f_ghosts_dirty;
       const bool virt = step_leaves_ghosts_virtual(h);
       if (!virt) settle_ghosts(h);

@@ -280,7 +280,7 @@ class Engine:
         self._ck(self.api.profile_steps(self._h, int(nsteps)), "profile_steps")
         out = {}
         for k in ("k_momentum", "k_set_bc", "k_jacobi", "k_jacobi_tb", "k_correct", "k_fct_x", "k_fct_y",
-                  "k_transport", "k_normals", "k_kappa", "k_predictor", "k_rhs", "k_jacobi_pair", "k_tm"):
+                  "k_transport", "k_normals", "k_kappa", "k_predictor", "k_rhs", "k_jacobi_pair", "k_tm", "k_tm_uv"):
             us, n = C.c_double(), C.c_int64()
             if self.api.get_profile(self._h, k.encode(), C.byref(us), C.byref(n)) != 0:
                 continue   # a kernel this build of the library does not have

@@ -827,6 +827,58 @@ def test_fused_transport_momentum_changes_no_value(hip_api, oracle_api, dtype, i
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ic,nx,ny", [("f64", 1, 384, 500), ("f32", 2, 290, 333), ("f64", 3, 300, 260)])
+def test_k_tm_batches_chain_across_calls(hip_api, oracle_api, dtype, ic, nx, ny):
+    """The k_tm batches chain (enqueue_steps_tm): every batch ends with the NEXT step's predictor in place -- its last
+    k_tm also stores u and v --, so from the second batch on no k_momentum / k_transport launch is left, across vof_step
+    calls too as long as nothing else touches the handle.  What the reference's u_star, v_star, rhs hold after the last
+    step sits in the other set of arrays until somebody asks (settle_ahead).  Against the plain sequence and the oracle:
+    calls of 16 / 8 / 2 steps with only a sync in between, then a read; a verb, a changed sigma and a single step in the
+    middle of the chain."""
+    a = engine(hip_api, nx, ny, dtype, "f32", ic=ic)
+    a.set_param("overlap_halves", 0)
+    a.set_param("fuse_tm", 1)
+    b = engine(hip_api, nx, ny, dtype, "f32", ic=ic)
+    b.set_param("overlap_halves", 0)
+    b.set_param("fuse_tm", 0)
+    o = engine(oracle_api, nx, ny, dtype, "f32", ic=ic)
+    everything = STATE + ("u_star", "v_star", "rhs")
+
+    def run(calls):
+        for n in calls:
+            a.step(n)
+            a.sync()
+        for e in (b, o):
+            e.step(sum(calls))
+
+    run((1,))                                   # the eager first step
+    run((16, 8, 2, 16))                         # four calls of one or two batches each, all but the first batch chained to the one before
+    chained = a.get_counter("tm_chained_batches")
+    assert chained >= 3
+    assert a.get_counter("courant_violations") == o.get_counter("courant_violations")
+    assert_fields_same(a, b, everything, ctx="chained batches, %s %dx%d step %d" % (dtype, nx, ny, a.istep))
+    assert_fields_same(a, o, ctx="chained batches / oracle, step %d" % a.istep)
+    run((8, 3, 8))                              # 8, then 2 + a single step (which forms its own predictor), then 8 again
+    assert a.get_counter("tm_chained_batches") == chained + 1
+    assert_fields_same(a, b, everything, ctx="a single step inside the chain, step %d" % a.istep)
+    run((16,))
+    for e in (a, b, o):                         # verbs on a handle that is ahead: they see the LAST step's u*, v* (and write mx, my, kappa: the other set)
+        e.cal_nu_rho()
+        e.solve_p_jacobi(3)
+        e.update_uv()
+        e.get_normal_young()
+    assert_fields_same(a, b, everything + ("rho", "nu", "mx", "my", "kappa"), ctx="verbs behind a chained batch, step %d" % a.istep)
+    assert_fields_same(a, o, STATE + ("u_star", "v_star", "rho", "nu", "mx", "my", "kappa"), ctx="verbs behind a chained batch / oracle, step %d" % a.istep)
+    run((16,))
+    for e in (a, b, o):
+        e.set_param("sigma", 0.05)              # the predictor formed ahead used the old value: it must not be used
+    run((16, 2))
+    assert_fields_same(a, b, everything, ctx="sigma changed behind a chained batch, step %d" % a.istep)
+    assert_fields_same(a, o, ctx="chained batches / oracle, step %d" % a.istep)
+    assert a.get_counter("tm_steps") >= 100 and b.get_counter("tm_steps") == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,ic,nx,ny", [("f64", 1, 2048, 2048), ("f64", 2, 1536, 3000), ("f32", 3, 2048, 2048)])
 def test_fused_transport_momentum_mid_size_twice(hip_api, dtype, ic, nx, ny):
     """k_tm on grids of a few million cells, twice, against the plain sequence.  The store-data hazard of round 4 (a

@@ -12,6 +12,7 @@ import argparse
 import collections
 import csv
 import json
+import re
 import os
 import sys
 
@@ -75,11 +76,13 @@ def main():
             from vof2d._lib import kernel_source_hash
             rec = {"nx": a.nx, "ny": a.ny, "dtype": a.dtype, "tag": a.tag, "hbm_bytes_per_launch": {}, "kernel_source_sha256": kernel_source_hash(),
                    "rule": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes", "kernels": {}}
-            for key, pat in (("tm", "k_tm<"), ("pair", "k_jacobi_pair<"), ("momentum", "k_momentum<"), ("transport", "k_transport<"), ("tb", "k_jacobi_tb<")):
-                vs = [(2 * v["fetch_kib"] + v["write_kib"]) * 1024 for k, v in agg.items() if pat in k and "fetch_kib" in v and "write_kib" in v]
+            # (k_tm's fourth template argument: the launch also stores u and v -- the last of a batch, "k_tm_uv" in the in-situ profiles)
+            for key, pat in (("tm", r"k_tm<[^,]+, \d+, (true|false), false,"), ("tm_uv", r"k_tm<[^,]+, \d+, (true|false), true,"), ("pair", r"k_jacobi_pair<"),
+                             ("momentum", r"k_momentum<"), ("transport", r"k_transport<"), ("tb", r"k_jacobi_tb<")):
+                vs = [(2 * v["fetch_kib"] + v["write_kib"]) * 1024 for k, v in agg.items() if re.search(pat, k) and "fetch_kib" in v and "write_kib" in v]
                 if vs:
                     rec["hbm_bytes_per_launch"][key] = sum(vs) / len(vs)
-                    rec["kernels"][key] = [k for k in agg if pat in k]
+                    rec["kernels"][key] = [k for k in agg if re.search(pat, k)]
             json.dump(rec, open(os.path.join(out, "tm_pmc.json"), "w"), indent=1)
             return
         if a.no_json:
