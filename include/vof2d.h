@@ -106,8 +106,12 @@ int vof_post_process_f(vof2d_handle h);             /* :452-455 */
  * kernel schedule: on a full domain four launches per step -- k_momentum, two
  * five-sweep k_jacobi_tb, k_transport -- replayed from a hipGraph (the first step after set_init_F /
  * set_field / a single verb runs eagerly with the intermediate boundary launches the reference's
- * :518 / :525 stand for; steady-state steps are replayed in batches of eight, then two, per graph launch).
- * rho/nu/kappa scratch is not materialised. */
+ * :518 / :525 stand for; steady-state steps are replayed in batches of 16 / 8 / 2 per graph launch, as chains of
+ * launches on row blocks); large fp64 grids that are mostly gas run two launches per step --
+ * k_jacobi_pair (ten sweeps) and k_tm (the step's transport + the next step's momentum), DESIGN.md 3.5 / 3.6 -- in
+ * batches of 32 / 8 / 2 that chain.  Whatever the form, F u v p u_star v_star rhs read back after n steps are the
+ * reference's after n steps.  rho / nu / mx / my / kappa scratch is not materialised (the k_tm form uses mx, my,
+ * kappa as its second set of u_star, v_star, rhs arrays). */
 int vof_step(vof2d_handle h, int64_t nsteps);
 /* The same step split at the points where a field becomes final, for drivers that overlap the
  * halo exchange with compute (vof2d/strips.py, vof_step_exchange):

@@ -353,6 +353,14 @@ void enqueue_steps_tm(vof2d_ctx* h, int64_t first_step, int K) {
   h->jpair_active = false;
   // (K swaps, an even number: the host's view of the pairs is back where it was)
 }
+// the one k_momentum launch in front of the first batch of a chain (its planner block plans the geometry of the Jacobi
+// kernel the batch will run)
+template <typename T>
+void enqueue_tm_head(vof2d_ctx* h, int par) {
+  h->jpair_active = L<T>::jacobi_pair_ok(h);
+  L<T>::momentum(h, true, par);
+  h->jpair_active = false;
+}
 // The handle leaves the chained k_tm batches (a field is read or written from outside, a verb, a parameter): the
 // reference's u_star, v_star, rhs after the last step are in the other set of arrays -- copy them into the host's view.
 int settle_ahead(vof2d_ctx* h) {

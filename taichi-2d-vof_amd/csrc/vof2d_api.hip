@@ -400,7 +400,7 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
           // the k_tm batches chain: each ends with the next step's predictor in place (enqueue_steps_tm); only the first
           // after anything else needs its k_momentum launched in front
           if (h->ahead) h->tm_chained += 1;
-          else DISPATCH_T(h, L<double>::momentum(h, true, par), L<float>::momentum(h, true, par));
+          else DISPATCH_T(h, enqueue_tm_head<double>(h, par), enqueue_tm_head<float>(h, par));
           h->ahead = true;
         } else h->ahead = false;
         if (hipGraphLaunch(GB[b][par][ori], h->stream) != hipSuccess) { h->istep -= 1; return fail(h, VOF_EHIP, "hipGraphLaunch of a step batch"); }
@@ -836,7 +836,7 @@ int vof_profile_steps(vof2d_handle h, int64_t nsteps) {
       for (int b = vof2d_ctx::kStepBatches - 1; b >= 0; --b)
         if (nsteps - done >= batch_steps(h, 1, b) && 1 + batch_steps(h, 1, b) * per_tm_step <= vof2d_ctx::kMaxTimed && batch_steps(h, 1, b) > K) K = batch_steps(h, 1, b);
       if (1 + K * per_tm_step > vof2d_ctx::kMaxTimed) { h->timed = -1; return fail(h, VOF_ESTATE, "a k_tm batch of two steps has more launches than the profiling event pool"); }
-      if (!h->ahead) DISPATCH_T(h, L<double>::momentum(h, true, (int)((h->istep + 1) & 1)), L<float>::momentum(h, true, (int)((h->istep + 1) & 1)));
+      if (!h->ahead) DISPATCH_T(h, enqueue_tm_head<double>(h, (int)((h->istep + 1) & 1)), enqueue_tm_head<float>(h, (int)((h->istep + 1) & 1)));
       h->ahead = true;
       DISPATCH_T(h, enqueue_steps_tm<double>(h, h->istep + 1, K), enqueue_steps_tm<float>(h, h->istep + 1, K));
       h->istep += K;
