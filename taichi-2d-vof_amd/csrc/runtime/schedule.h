@@ -366,10 +366,17 @@ void enqueue_tm_head(vof2d_ctx* h, int par) {
 int settle_ahead(vof2d_ctx* h) {
   if (!h->ahead) return VOF_OK;
   h->ahead = false;
-  const size_t bytes = h->field_elems * h->esz;
-  HIPCHK(h, hipMemcpyAsync(h->fld[fUS], h->fld[fMX], bytes, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->fld[fVS], h->fld[fMY], bytes, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->fld[fRHS], h->fld[fKAPPA], bytes, hipMemcpyDeviceToDevice, h->stream));
+  // exactly the cells the predictor writes (:206-233, :238-243) -- u* on i in [2, nx], v* on j in [2, ny], rhs on the
+  // interior: everything else of the other set is whatever a verb left in mx, my, kappa
+  auto copy = [&](int dst, int src, int i0, int j0) -> hipError_t {
+    const size_t pitch = (size_t)h->g.pitch * h->esz;
+    const size_t off = ((size_t)(i0 - h->d.row_lo) * h->g.pitch + h->g.col0 + j0) * h->esz;
+    return hipMemcpy2DAsync(reinterpret_cast<char*>(h->fld[dst]) + off, pitch, reinterpret_cast<const char*>(h->fld[src]) + off, pitch,
+                            (size_t)(h->g.ny - j0 + 1) * h->esz, (size_t)(h->g.nx - i0 + 1), hipMemcpyDeviceToDevice, h->stream);
+  };
+  HIPCHK(h, copy(fUS, fMX, 2, 1));
+  HIPCHK(h, copy(fVS, fMY, 1, 2));
+  HIPCHK(h, copy(fRHS, fKAPPA, 1, 1));
   return VOF_OK;
 }
 
