@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--dt", type=float, default=1e-6)
     ap.add_argument("--modes", default="compute,native-overlap,native-two,native-after,native-fused,compute-pairs,native-pairs")
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--param", action="append", default=[], help="knob=value set on the strip's handle (e.g. tm_rows=52)")
     a = ap.parse_args()
     modes = a.modes.split(",")
     need_torch = any(m.startswith("torch") for m in modes)
@@ -42,6 +43,8 @@ def main():
         stream = torch.cuda.Stream()
         stream_ptr = stream.cuda_stream
     e = Engine(api, make_desc(api, a.nx, a.ny, "f64", "f32", rows=rows, own=own, device=0, dt=a.dt), stream=stream_ptr)
+    for kv in a.param:
+        e.set_param(kv.split("=")[0], float(kv.split("=")[1]))
     e.set_init_F(1)
     e.step(1)                  # (the first step after set_init_F: the schedule with the reference's intermediate set_BC calls)
     e.comm_init(comm_unique_id(api), 0, 1, loopback=True)
