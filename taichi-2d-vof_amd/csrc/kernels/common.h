@@ -68,7 +68,9 @@ enum : int {
   ABL_PRIO0 = 4,       // NO s_setprio 1 for the first wave of the pair (the product runs it at priority 1)
   ABL_PRIO1 = 8,       // s_setprio 1 for the second
   ABL_IDLE1 = 16,      // the second wave only keeps the barriers
-  ABL_PASS0 = 32       // the first wave hands its input rows on without computing
+  ABL_PASS0 = 32,      // the first wave hands its input rows on without computing
+  ABL_NO_UPRED = 64,   // k_tm: the momentum wave leaves out the advection / diffusion terms of u* (what would another wave's taking them over buy?)
+  ABL_NO_VPRED = 128   // ... of v* too
 };
 template <typename T, int V>
 struct Row {  // one row of a wave tile as seen by a lane: j0-1 | j0..j0+V-1 | j0+V

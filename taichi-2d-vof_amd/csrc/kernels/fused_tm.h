@@ -415,6 +415,7 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
           T dudy = upwind_diff<T>(v_here > 0, u00, u0m, u0p) * dyi;
           ou = (u00 + dt * (nu00 * (um0 - (T)2 * u00 + up0) * dxi2 + nu00 * (u0m - (T)2 * u00 + u0p) * dyi2 -
                             u00 * dudx - v_here * dudy + c.gx + fxf[q]));
+          if constexpr ((ABL & ABL_NO_UPRED) != 0) ou = u00 + dt * (um0 + c.gx + fxf[q]);   // (timing only)
         }
         {
           T u_here = (T)0.25 * (u0m + u00 + upm + up0);
@@ -422,6 +423,7 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
           T dvdy = upwind_diff<T>(v00 > 0, v00, v0m, v0p) * dyi;
           ov = (v00 + dt * (nu00 * (vm0 - (T)2 * v00 + vp0) * dxi2 + nu00 * (v0m - (T)2 * v00 + v0p) * dyi2 -
                             u_here * dvdx - v00 * dvdy + c.gy + fyf[q]));
+          if constexpr ((ABL & ABL_NO_VPRED) != 0) ov = v00 + dt * (vm0 + c.gy + fyf[q]);   // (timing only)
         }
         const int j = j0 + q;
         us2[q] = (okP && (IN || i >= 2) && dom[q]) ? ou : (T)0;

@@ -515,6 +515,7 @@ int vof_get_istep(vof2d_handle h, int64_t* istep) {
 }
 int vof_set_istep(vof2d_handle h, int64_t istep) {
   if (!h) return VOF_EINVAL;
+  (void)settle_ahead(h);   // (the plan the last k_tm left is of the parity that was to follow)
   h->istep = istep;
   return VOF_OK;
 }
@@ -928,7 +929,7 @@ extern "C" int vof_debug_time_kernel(vof2d_handle h, int32_t which, int32_t abl,
   for (int r = 0; r < reps; ++r) {
 #define ABL_CASE(a) case a: if (which == 0) dbg_pair<a>(h, plan); else if (which == 1) dbg_tm<true, a>(h); else dbg_tm<false, a>(h); break;
     switch (abl) {
-      ABL_CASE(0) ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(32) ABL_CASE(48) ABL_CASE(19) ABL_CASE(35)
+      ABL_CASE(0) ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(32) ABL_CASE(48) ABL_CASE(19) ABL_CASE(35) ABL_CASE(64) ABL_CASE(192)
       default: return fail(h, VOF_EINVAL, "ablation not instantiated");
     }
 #undef ABL_CASE
