@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T*
   bool planned = false;
   if (tp.masks != nullptr) {
     const unsigned long long* pl = tp.plan;
-    if (pl[0] != 0ull) {
+    if (pl[0] == plan_key(tp)) {   // an active plan of this launch's own geometry
       const unsigned long long e = pl[1 + wave];    // scalar loads: nobody writes the plan during the launch
       tj = (int)(e & 0xffull);
       ra = (int)((e >> 8) & 0xfffffffull);

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(128) void k_jacobi_pair(Geom g, Consts<T> c, const 
   bool planned = false;
   if (tp.masks != nullptr) {
     const unsigned long long* pl = tp.plan;
-    if (pl[0] != 0ull) {
+    if (pl[0] == plan_key(tp)) {   // an active plan of this launch's own geometry
       const unsigned long long e = pl[1 + pair];
       tj = (int)(e & 0xffull);
       ra = (int)((e >> 8) & 0xfffffffull);

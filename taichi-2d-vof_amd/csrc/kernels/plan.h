@@ -32,6 +32,11 @@ struct TbPlan {
   unsigned long long* plan;
   int ntt, R, waves, par;             // tile columns (<= TB_COLS), uniform chunk length, waves of a launch, istep & 1
 };
+// plan[0] of an active plan: 1 + the geometry it was planned for.  A launch reads the plan only if that is its own
+// geometry (a plan of k_jacobi_tb's tile columns read by k_jacobi_pair would leave rows out); anything else is "no plan".
+__device__ __forceinline__ unsigned long long plan_key(const TbPlan& tp) {
+  return 1ull | ((unsigned long long)(unsigned)tp.waves << 1) | ((unsigned long long)(unsigned)tp.R << 33) | ((unsigned long long)(unsigned)tp.ntt << 48);
+}
 __device__ __forceinline__ unsigned long long plan_pack(int tj, int ra, int rb) {
   return (unsigned long long)(unsigned)tj | ((unsigned long long)(unsigned)ra << 8) | ((unsigned long long)(unsigned)rb << 36);
 }
@@ -101,7 +106,7 @@ __device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) 
       tp.masks[tb_word(tp.par ^ 1, lane, 0) + w] = 0ull;   // this step's launches report into the other set
       sh.band[lane][w] = mine[w];
     }
-    if (lane == 0) tp.plan[0] = any ? 1ull : 0ull;
+    if (lane == 0) tp.plan[0] = any ? plan_key(tp) : 0ull;
   }
   if (!any) return;                             // block-uniform
   __syncthreads();

@@ -308,7 +308,7 @@ struct L {
     int ntt = 0;
     int R;
     long waves;
-    if (h->jpair_active) {   // the step's Jacobi launches are k_jacobi_pair's: the plan's "waves" are pairs on 104-column tiles
+    if (h->jpair_active) {   // the step's Jacobi launches are k_jacobi_pair's: the plan's "waves" are pairs on 108-column tiles (jacobi_pair_geom); a plan is only ever read by the kernel it was planned for -- enqueue_tm_head, tm5_head
       R = jacobi_pair_geom(h, ntt);
       waves = (long)((h->g.ihi - h->g.ilo + R) / R) * ntt;
     } else {

@@ -765,7 +765,7 @@ int vof_get_counter(vof2d_handle h, const char* name, int64_t* value) {
     unsigned long long v = 0;
     HIPCHK(h, hipMemcpyAsync(&v, h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64), sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    *value = (int64_t)v;
+    *value = v ? 1 : 0;   // (plan[0] of an active plan carries its geometry: plan_key)
     return VOF_OK;
   }
   if (!strcmp(name, "pair_launches")) {   // k_jacobi_pair launches replayed from batch graphs
