@@ -213,6 +213,17 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int n) {
   const int q = n >> 3, r = n & 7, x = b & 7;
   return x * q + (x < r ? x : r) + (b >> 3);
 }
+// The pair kernels' order: windows of 8 * kXcdGroup consecutive blocks (in flight together, in index order: one compact
+// band), inside a window XCD x takes kXcdGroup consecutive logical blocks -- horizontally adjacent tiles, which share
+// their overlap columns through that XCD's L2.  The last, partial window keeps its order.
+constexpr int kXcdGroup = 10;
+__device__ __forceinline__ int xcd_grouped_block(int b, int n) {
+  constexpr int WIN = 8 * kXcdGroup;
+  const int base = (b / WIN) * WIN;
+  if (base + WIN > n) return b;
+  const int o = b - base;
+  return base + (o & 7) * kXcdGroup + (o >> 3);
+}
 
 // wave -> (column tile, row chunk).  Rows [first, last] are split in chunks of R.
 template <int V>

@@ -496,7 +496,14 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
   }
   TmRing<T, V>& ring = *reinterpret_cast<TmRing<T, V>*>(smem);
   WaveTimer wt_(WT_TM);
-  const int pair = (int)blockIdx.x - plan_blocks;
+  int pair = (int)blockIdx.x - plan_blocks;
+  // Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch"; observed, not promised: only speed depends on
+  // it) and each XCD has its own L2.  Within a window of 8 * kXcdGroup consecutive workgroups -- about two chunk rows, in
+  // flight together -- XCD x takes kXcdGroup ADJACENT tiles, whose 16 overlapping columns it then finds in its own L2
+  // instead of fetching them a second time: k_tm 279 -> 270 us (4096^2, in the step), with the same in k_jacobi_pair
+  // 0.4375 -> 0.430 ms/step (profiles/r05_xcd_groups_ab.txt).  Unlike xcd_contiguous_block the dispatch order stays one
+  // compact band.
+  pair = xcd_grouped_block(pair, (int)gridDim.x - plan_blocks);
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: transport, 1: momentum
   const int lane = threadIdx.x & 63;
   const int tj = pair % ntf, ch = pair / ntf;

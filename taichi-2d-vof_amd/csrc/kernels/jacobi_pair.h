@@ -275,7 +275,9 @@ __global__ __launch_bounds__(128) void k_jacobi_pair(Geom g, Consts<T> c, const 
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   // pair -> (tile column tj, rows [ra, rb]): chunks of R rows of every column, or the equal-cost chunks of the step's plan
-  int tj = pair % ntt, ra = first + (pair / ntt) * R, rb = ra + R - 1;
+  int upair;          // the uniform layout's index
+  upair = xcd_grouped_block(pair, (int)gridDim.x);   // (XCD x takes adjacent tiles of a window: see k_tm)
+  int tj = upair % ntt, ra = first + (upair / ntt) * R, rb = ra + R - 1;
   bool planned = false;
   if (tp.masks != nullptr) {
     const unsigned long long* pl = tp.plan;

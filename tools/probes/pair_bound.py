@@ -53,7 +53,8 @@ e.set_init_F(a.ic)
 NAMES = {0: "as shipped", 1: "fixed-row loads", 2: "no store", 3: "fixed-row loads, no store", 4: "wave 0 NOT at prio 1",
          8: "wave 1 at prio 1 too", 16: "wave 1 idle", 32: "wave 0 passes rows on", 48: "wave 0 passes rows on, wave 1 idle",
          19: "wave 1 idle, no HBM stream", 35: "wave 0 passes rows on, no HBM stream",
-         64: "momentum wave without the advection / diffusion of u*", 192: "... of u* and v*"}
+         64: "momentum wave without the advection / diffusion of u*", 192: "... of u* and v*",
+         256: "as shipped, caches flushed before every launch", 257: "fixed-row loads, caches flushed"}
 ABLS = (0, 1, 2, 3, 4, 8, 16, 32, 48, 19, 35)
 KERNELS = ((0, 1, "k_jacobi_pair (work plan)"), (0, 0, "k_jacobi_pair (uniform chunks)"), (1, 0, "k_tm y first"), (2, 0, "k_tm x first"))
 
@@ -117,13 +118,13 @@ for at in [int(x) for x in a.at.split(",")]:
         base = []
         line = []
         for rnd in range(2):
-            for abl in ABLS + ((64, 192) if which else ()):
+            for abl in ABLS + ((64, 192) if which else ()) + (256, 257):
                 us = t(which, abl, plan)
                 if abl == 0:
                     base.append(us)
                 line.append((rnd, abl, us))
         print(" %s: %s" % (label, " | ".join("%s %.1f / %.1f" % (NAMES[abl], [u for r, b, u in line if b == abl][0], [u for r, b, u in line if b == abl][1])
-                                             for abl in ABLS + ((64, 192) if which else ()))), flush=True)
+                                             for abl in ABLS + ((64, 192) if which else ()) + (256, 257))), flush=True)
     if a.map:
         for which, kid, plan, stride, label in ((1, 14, 0, 112, "k_tm y first"), (0, 13, 0, 108, "k_jacobi_pair (uniform chunks)"), (0, 13, 1, 108, "k_jacobi_pair (work plan)")):
             print(" wave map of one launch of %s:" % label)
