@@ -133,7 +133,7 @@ template <typename T, int V, int TS, bool SQ, bool RESID = false, bool BS = fals
 __global__ __launch_bounds__(256) void k_jacobi_tb(Geom g, Consts<T> c, const T* __restrict__ p,
                                                     const T* __restrict__ rhs, T* __restrict__ pn, int R,
                                                     int ntt, unsigned long long* __restrict__ norm_bits = nullptr,
-                                                    TbPlan tp = TbPlan{nullptr, nullptr, 0, 0, 0, 0}, int first = 1, int last = 0) {
+                                                    TbPlan tp = TbPlan{nullptr, nullptr, 0, 0, 0, 0, 0}, int first = 1, int last = 0) {
   // rows [first, last] of the result are produced (last < first: all of [g.ilo, g.ihi])
   if (last < first) { first = g.ilo; last = g.ihi; }
   // SQ (dxi2 == dyi2 bitwise, i.e. square cells): the stencil has ONE off-diagonal coefficient, so

@@ -26,11 +26,12 @@ namespace vof {
 // Jacobi launches in the fused step): it runs beside the other blocks, off the critical path.
 constexpr int TB_BANDS = 64;          // row bands of the hit masks
 constexpr int TB_COLS = 128;          // tile columns the masks cover (two 64-bit words per band): grids up to ~14 800 wide
-constexpr int TB_SLOW10 = 20;         // cost of a band row in tenths of an ordinary row
+constexpr int TB_SLOW10 = 20;         // cost of a band row in tenths of an ordinary row (k_jacobi_tb; the pair kernel's: TbPlan::slow10)
 struct TbPlan {
   unsigned long long* masks;          // nullptr: no plan (uniform layout)
   unsigned long long* plan;
   int ntt, R, waves, par;             // tile columns (<= TB_COLS), uniform chunk length, waves of a launch, istep & 1
+  int slow10;                         // cost of a row of a reported band in tenths of an ordinary row (0: TB_SLOW10)
 };
 // plan[0] of an active plan: 1 + the geometry it was planned for.  A launch reads the plan only if that is its own
 // geometry (a plan of k_jacobi_tb's tile columns read by k_jacobi_pair would leave rows out); anything else is "no plan".
@@ -60,26 +61,26 @@ struct TbPlanShared {
 __device__ __forceinline__ bool tb_bit(const TbPlanShared& sh, int b, int j) { return ((sh.band[b][j >> 6] >> (j & 63)) & 1ull) != 0ull; }
 // cost of rows [0, min(b * bh, rows)) of a tile column, in tenths of a row: 10 per row, TB_SLOW10 per row of a
 // reported band.  Bands 0 .. rows / bh - 1 are bh rows long, the next one holds the remainder, the rest are empty.
-__device__ __forceinline__ unsigned tb_prefix(unsigned long long colbits, int b, int rows, int bh) {
+__device__ __forceinline__ unsigned tb_prefix(unsigned long long colbits, int b, int rows, int bh, int slow10) {
   const int nfull = rows / bh, part = rows - nfull * bh;       // (bh >= 1: rows >= 1 on every handle)
   const unsigned long long upto = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
   const unsigned long long full = nfull >= 64 ? ~0ull : ((1ull << nfull) - 1ull);
   int slow_rows = bh * __popcll(colbits & upto & full);
   if (part > 0 && nfull < b && nfull < 64 && ((colbits >> nfull) & 1ull)) slow_rows += part;
   const int before = b * bh < rows ? b * bh : rows;
-  return 10u * (unsigned)before + (unsigned)(TB_SLOW10 - 10) * (unsigned)slow_rows;
+  return 10u * (unsigned)before + (unsigned)(slow10 - 10) * (unsigned)slow_rows;
 }
 // row position (0 .. rows) where the cumulative cost of column j reaches T
-__device__ __forceinline__ int tb_pos(const TbPlanShared& sh, int j, unsigned T, int rows, int bh) {
+__device__ __forceinline__ int tb_pos(const TbPlanShared& sh, int j, unsigned T, int rows, int bh, int slow10) {
   const unsigned long long colbits = sh.col[j];
   int lo = 0, hi = TB_BANDS;           // largest b with prefix(b) <= T
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (tb_prefix(colbits, mid, rows, bh) <= T) lo = mid; else hi = mid;
+    if (tb_prefix(colbits, mid, rows, bh, slow10) <= T) lo = mid; else hi = mid;
   }
   const bool slow = ((colbits >> lo) & 1ull) != 0ull;
-  const unsigned rest = T - tb_prefix(colbits, lo, rows, bh);
-  int pos = lo * bh + (int)(slow ? rest / (unsigned)TB_SLOW10 : rest / 10u);
+  const unsigned rest = T - tb_prefix(colbits, lo, rows, bh, slow10);
+  int pos = lo * bh + (int)(slow ? rest / (unsigned)slow10 : rest / 10u);
   const int bend = (lo + 1) * bh;
   if (pos > bend) pos = bend;
   return pos < rows ? pos : rows;
@@ -90,6 +91,7 @@ __device__ __forceinline__ int tb_wave_sum(int v) {
 }
 __device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) {
   constexpr int CW = TB_COLS / 64;
+  const int slow10 = tp.slow10 > 10 ? tp.slow10 : TB_SLOW10;
   const int t = threadIdx.x, lane = t & 63;
   const int rows = g.ihi - g.ilo + 1, bh = (rows + TB_BANDS - 1) / TB_BANDS;
   unsigned long long mine[CW];                  // band `lane` (nobody writes the read set during this step)
@@ -118,7 +120,7 @@ __device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) 
       unsigned long long bits = 0ull;
       for (int b = 0; b < TB_BANDS; ++b) bits |= tb_bit(sh, b, j) ? (1ull << b) : 0ull;
       sh.col[j] = bits;
-      cost[c] = j < tp.ntt ? tb_prefix(bits, TB_BANDS, rows, bh) : 0u;
+      cost[c] = j < tp.ntt ? tb_prefix(bits, TB_BANDS, rows, bh, slow10) : 0u;
     }
     unsigned total = 0;
 #pragma unroll
@@ -184,9 +186,9 @@ __device__ void tb_make_plan(const Geom& g, const TbPlan& tp, TbPlanShared& sh) 
       }
       const int j = lo, n = sh.n[j], k = w - sh.first[j];
       // chunk k of column j: between the rows where the cumulative cost reaches k / n and (k + 1) / n of the column's
-      const unsigned cost = tb_prefix(sh.col[j], TB_BANDS, rows, bh);
-      const int a = k == 0 ? 0 : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)k) / (unsigned)n), rows, bh);
-      const int b = k == n - 1 ? rows : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)(k + 1)) / (unsigned)n), rows, bh);
+      const unsigned cost = tb_prefix(sh.col[j], TB_BANDS, rows, bh, slow10);
+      const int a = k == 0 ? 0 : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)k) / (unsigned)n), rows, bh, slow10);
+      const int b = k == n - 1 ? rows : tb_pos(sh, j, (unsigned)(((unsigned long long)cost * (unsigned)(k + 1)) / (unsigned)n), rows, bh, slow10);
       e = plan_pack(j, g.ilo + a, g.ilo + b - 1);   // (b == a: an empty chunk, the wave returns at once)
     }
     tp.plan[1 + w] = e;

@@ -185,6 +185,12 @@ struct vof2d_ctx {
   int64_t tm_chained = 0;    // k_tm batches that started without a k_momentum launch (counter "tm_chained_batches")
   int jpair = 1;             // knob "jacobi_pair": the k_tm batch graphs run each two five-sweep launches as one k_jacobi_pair launch
   int jpair_rows = 0;        // rows per pair chunk (0 = one residency round of pairs)
+  // knobs "pair_slow10", "tb_slow10": what the planner takes a row of a reported band to cost, in tenths of an ordinary row.
+  // k_jacobi_pair, 4096^2 dam-break, us per launch in steps 301-350 / ms per step over steps 61-660: 20 146.6 / 0.4454, 26 132.0 / 0.4355,
+  // 32 127.2 / 0.4312, 40 128.4 / 0.4328, 50 129.8 / 0.4338 (the cold tier costs more against the FAST sub-iterations than it did
+  // against round 4's rows)
+  int pair_slow10 = 32;
+  int tb_slow10 = 20;
   int pair_vec4 = 0;         // knob "pair_vec4": fp32 pair kernels with four columns per lane (256-column tiles)
   bool jpair_active = false; // the launches being enqueued are k_jacobi_pair's (tb_plan describes their geometry)
   bool jpair_captured = false;   // the k_tm batch graphs the handle holds contain k_jacobi_pair launches

@@ -24,7 +24,7 @@ void dbg_tm(vof2d_ctx* h) {
   constexpr int ST = 64 * V - 2 * TmGeom::HF;
   const int ntf = (h->g.ny + ST - 1) / ST, first = h->g.ilo, last = h->g.ihi;
   const int R = L<T>::tm_chunk_rows(h, last - first + 1, ntf, resident_blocks(h, k_tm<T, V, YFIRST, false, true, ABL>, 128));
-  const TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
+  const TbPlan tp{nullptr, nullptr, 0, 0, 0, 0, 0};
   const unsigned pairs = (unsigned)(((last - first + R) / R) * ntf);
   launch_block(h, kTM, k_tm<T, V, YFIRST, false, true, ABL>, dim3(pairs), 128u, 0, h->g, L<T>::C(h), (const T*)F_<T>(h, fF), F_<T>(h, fF2), ntf,
                (const T*)F_<T>(h, fUS), (const T*)F_<T>(h, fVS), (const T*)F_<T>(h, fP), F_<T>(h, fU), F_<T>(h, fV),

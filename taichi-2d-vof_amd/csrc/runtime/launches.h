@@ -301,7 +301,7 @@ struct L {
   // the work plan of the step's five-sweep launches (see tb_make_plan): active on parity-keyed step
   // sequences (adapt_par = istep & 1), square or not, two columns per lane, up to TB_COLS tile columns
   static TbPlan tb_plan(vof2d_ctx* h, int adapt_par) {
-    TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
+    TbPlan tp{nullptr, nullptr, 0, 0, 0, 0, 0};
     if (adapt_par < 0 || !h->tb_adapt || h->tb < 5 || h->tb_rows > 0) return tp;
     const Consts<T> cc = C(h);
     const bool sq = cc.dxi2 == cc.dyi2 && !h->tb_general;
@@ -319,6 +319,7 @@ struct L {
     tp.masks = h->d_tbmask;
     tp.plan = h->d_tbmask + 2 * TB_BANDS * (TB_COLS / 64);
     tp.ntt = ntt; tp.R = R; tp.waves = (int)waves; tp.par = adapt_par;
+    tp.slow10 = h->jpair_active ? h->pair_slow10 : h->tb_slow10;   // (what a row of a reported band costs: per kernel)
     return tp;
   }
   template <int TS, int VV>
@@ -327,7 +328,7 @@ struct L {
     if (last < first) { first = h->g.ilo; last = h->g.ihi; }
 
     unsigned long long* none = nullptr;
-    TbPlan tp{nullptr, nullptr, 0, 0, 0, 0};
+    TbPlan tp{nullptr, nullptr, 0, 0, 0, 0, 0};
     if (TS == 5 && VV == V) tp = tb_plan(h, adapt_par);
     // (with a plan the launch holds the waves of the whole grid's plan, whatever part of the rows it is for: every
     // wave takes the part of its planned chunk inside [first, last], or nothing)
