@@ -34,6 +34,8 @@ def child(a):
     if a.strip:
         n = 8192
         kw = dict(rows=(3 * 1024 + 1 - 16, 4 * 1024 + 16), own=(3 * 1024 + 1, 4 * 1024), dt=1e-6)
+    if a.dt > 0:
+        kw["dt"] = a.dt
     e = Engine(api, make_desc(api, n, n, a.dtype, "f32", device=0, **kw))
     for k, v in (kv.split("=") for kv in a.param):
         e.set_param(k, float(v))
@@ -75,6 +77,7 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("-ic", type=int, default=1)
     ap.add_argument("--strip", action="store_true")
+    ap.add_argument("--dt", type=float, default=0.0, help="time step (0: the library's default; 8192^2 needs 1e-6)")
     ap.add_argument("--param", action="append", default=[], help="knob=value set on every engine")
     ap.add_argument("--env", action="append", default=[], help="NAME=value in the environment of every run")
     ap.add_argument("--child", default=None, help=argparse.SUPPRESS)
@@ -88,7 +91,7 @@ def main():
                 print("missing", lib_path(v))
                 continue
             cmd = [sys.executable, os.path.abspath(__file__), "--child", v, "--n", str(a.n), "--steps", str(a.steps),
-                   "--dtype", a.dtype, "-ic", str(a.ic)] + (["--strip"] if a.strip else []) + sum((["--param", p] for p in a.param), [])
+                   "--dtype", a.dtype, "-ic", str(a.ic), "--dt", str(a.dt)] + (["--strip"] if a.strip else []) + sum((["--param", p] for p in a.param), [])
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
                                env=dict(os.environ, **dict(kv.split("=", 1) for kv in a.env)))
             if r.returncode != 0:
