@@ -145,6 +145,27 @@ for at in [int(x) for x in a.at.split(",")]:
             0, len(t0), (t1.max() - base) / 100.0, dur.mean(), np.percentile(dur, 10), np.median(dur), np.percentile(dur, 90), dur.max(),
             dur.sum() / ((t1.max() - base) / 100.0 * 3072)))
         print("   waves in flight (20 slices): " + " ".join("%d" % int(((t0 <= x) & (t1 > x)).sum()) for x in mid), flush=True)
+        # what would another dispatch order of the same pairs buy?  Greedy list scheduling of the measured durations on the
+        # launch's pair slots (a pair = two consecutive waves), in three orders
+        import heapq
+        idx = np.nonzero(m)[0]
+        dp = np.array([dur[(idx // 2) == q].max() for q in np.unique(idx // 2)])
+        slots = int(np.array([int(((t0 <= x) & (t1 > x)).sum()) for x in mid]).max() // 2)
+
+        def span(order):
+            h = [0.0] * slots
+            heapq.heapify(h)
+            end = 0.0
+            for q in order:
+                s0 = heapq.heappop(h)
+                heapq.heappush(h, s0 + dp[q])
+                end = max(end, s0 + dp[q])
+            return end
+        n = len(dp)
+        med = np.median(dp)
+        two = [q for q in range(n) if dp[q] > 1.2 * med] + [q for q in range(n) if dp[q] <= 1.2 * med]
+        print("   list scheduling of the %d measured pair durations on %d slots: in dispatch order %.1f us, longest first %.1f, the pairs above 1.2 x the median first (%d of them) %.1f; sum / slots = %.1f" % (
+            n, slots, span(range(n)), span(np.argsort(-dp)), int((dp > 1.2 * med).sum()), span(two), dp.sum() / slots), flush=True)
     if a.rows:
         for knob, which, vals in (("tm_rows", 1, tuple(int(x) for x in a.tm_rows.split(","))), ("jacobi_pair_rows", 0, tuple(int(x) for x in a.pair_rows.split(",")))):
             res = []
