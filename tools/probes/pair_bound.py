@@ -164,6 +164,11 @@ for at in [int(x) for x in a.at.split(",")]:
         n = len(dp)
         med = np.median(dp)
         two = [q for q in range(n) if dp[q] > 1.2 * med] + [q for q in range(n) if dp[q] <= 1.2 * med]
+        for nb in (8, 16, 32):
+            edges_b = np.linspace(dp.min(), dp.max() + 1e-9, nb + 1)
+            cls = np.minimum(nb - 1, np.searchsorted(edges_b, dp, side="right") - 1)
+            order = [q for c in range(nb - 1, -1, -1) for q in range(n) if cls[q] == c]
+            print("   ... in %d duration classes, longest class first, dispatch order inside a class: %.1f us" % (nb, span(order)))
         print("   list scheduling of the %d measured pair durations on %d slots: in dispatch order %.1f us, longest first %.1f, the pairs above 1.2 x the median first (%d of them) %.1f; sum / slots = %.1f" % (
             n, slots, span(range(n)), span(np.argsort(-dp)), int((dp > 1.2 * med).sum()), span(two), dp.sum() / slots), flush=True)
     if a.rows:
