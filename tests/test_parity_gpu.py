@@ -917,6 +917,7 @@ def test_jacobi_pair_changes_no_value(hip_api, oracle_api, dtype, ic, n, ring, r
     a.set_param("fuse_tm", 1)
     a.set_param("jacobi_pair", 2)                 # (2: in fp32 too, where the default keeps the two launches)
     a.set_param("jacobi_pair_rows", rows)
+    a.set_param("pair_slow10", 20 + 10 * (n % 4))   # (what the planner takes a front row to cost: any weight, the same values)
     b = engine(hip_api, n, n, dtype, "f32", ic=ic, **kw)
     b.set_param("overlap_halves", 0)
     b.set_param("fuse_tm", 0)
