@@ -208,6 +208,14 @@ inline OwnedRows owned_rows(const vof2d_ctx* h) {
 // the first step's k_momentum: u*, v*, rhs of the owned rows (their halo rows arrive by exchange: mode 5's state)
 template <typename T>
 void tm5_head(vof2d_ctx* h) {
+  // The middle steps alternate u*, v* between their own arrays and mx, my, and a call may end with the host's view on
+  // the second pair: the cells the predictor never writes (u* on i = 1, v* on j = 1, ny + 1, the ghost cells) must hold
+  // the zeros the reference's never-written entries hold (S5), not what a verb (get_normal_young) left there.
+  if (h->alt_dirty) {
+    (void)hipMemsetAsync(h->fld[fMX], 0, h->field_elems * h->esz, h->stream);
+    (void)hipMemsetAsync(h->fld[fMY], 0, h->field_elems * h->esz, h->stream);
+    h->alt_dirty = false;
+  }
   const OwnedRows o = owned_rows(h);
   h->jpair_active = L<T>::jacobi_pair_ok(h);    // (the planner block plans the geometry of the kernel that will run)
   L<T>::momentum(h, true, (int)((h->istep + 1) & 1), o.lo, o.hi);

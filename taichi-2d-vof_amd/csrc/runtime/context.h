@@ -180,6 +180,7 @@ struct vof2d_ctx {
   int fuse_tm = -1;
   double gas_share = -1.0;   // what the rule saw (get_param "gas_share")
   bool tm_broken = false;    // the k_tm batch graphs could not be captured: the other form stays
+  bool alt_dirty = false;    // a verb or a field write left something in mx / my (the second u*, v* pair of the k_tm forms): cleared at the head of a strip call (tm5_head)
   bool ahead = false;        // u*, v*, rhs hold the predictor of step istep + 1 (the chained k_tm batches; settle_ahead)
   bool tm_rhs_alt = false;   // the k_tm launches being enqueued write rhs into the kappa array (the caller swaps the views)
   int64_t tm_chained = 0;    // k_tm batches that started without a k_momentum launch (counter "tm_chained_batches")

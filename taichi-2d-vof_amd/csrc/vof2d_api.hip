@@ -173,12 +173,14 @@ int vof_get_normal_young(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   settle_ghosts(h);
   DISPATCH_T(h, (L<double>::normals(h), L<double>::kappa(h)), (L<float>::normals(h), L<float>::kappa(h)));
+  h->alt_dirty = true;
   return ensure_ok(h);
 }
 int vof_advect_upwind(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   settle_ghosts(h);
   DISPATCH_T(h, L<double>::predictor<true>(h), L<float>::predictor<true>(h));
+  h->alt_dirty = true;
   return ensure_ok(h);
 }
 int vof_solve_p_jacobi(vof2d_handle h, int32_t n) {
@@ -592,6 +594,7 @@ int vof_set_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, const
   int rc = copy_rows_host(h, id, g0, g1, const_cast<void*>(src), nbytes, false);
   if (rc == VOF_OK && id == fF) rc = copy_rows_host(h, fF2, g0, g1, const_cast<void*>(src), nbytes, false);
   if (id == fF || id == fF2) { h->f_ghosts_dirty = true; if (h->fuse_tm == -1) h->tm_decided = false; }
+  if (id == fMX || id == fMY) h->alt_dirty = true;
   if (id == fU || id == fV) h->uv_ghosts_dirty = true;
   return rc;
 }
@@ -640,6 +643,7 @@ int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t 
                                dst->stream));
   if (dst->g.wall_lo && dst->g.wall_hi) {  // a full domain: the rows' neighbours' ghost cells may no longer mirror them
     if (id == fF) { dst->f_ghosts_dirty = true; if (dst->fuse_tm == -1) dst->tm_decided = false; }
+    if (id == fMX || id == fMY) dst->alt_dirty = true;
     if (id == fU || id == fV) dst->uv_ghosts_dirty = true;
   }
   return VOF_OK;
@@ -1078,6 +1082,7 @@ int vof_step_tm_piece(vof2d_handle h, int32_t piece) {
   if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
   if (!mode5_ok(h)) return fail(h, VOF_ESTATE, "the pair kernels need the fused transport and five-sweep Jacobi launches");
   if (h->f_ghosts_dirty || h->uv_ghosts_dirty) return fail(h, VOF_ESTATE, "the first step after set_init_F / set_field runs through vof_step");
+  (void)settle_ahead(h);   // (a full domain that ran chained k_tm batches: its u*, v*, rhs are the last step's from here on)
   if (piece == 0) {
     DISPATCH_T(h, tm5_head<double>(h), tm5_head<float>(h));
   } else if (piece == 1) {
@@ -1183,6 +1188,7 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
   if (!h->comm) return fail(h, VOF_ESTATE, "vof_comm_init has not been called");
   if (h->next_phase != 0) return fail(h, VOF_ESTATE, "a phased step (vof_step_phase) is in progress");
   HIPCHK(h, hipSetDevice(h->device));
+  (void)settle_ahead(h);   // (see vof_step_tm_piece)
   if (overlap == 5) return step_exchange_mode5(h, nsteps);
   const bool want_graph = !(h->d.flags & VOF_FLAG_NO_GRAPH);
   for (int64_t s = 0; s < nsteps; ++s) {

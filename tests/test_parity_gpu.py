@@ -876,6 +876,14 @@ def test_k_tm_batches_chain_across_calls(hip_api, oracle_api, dtype, ic, nx, ny)
     assert_fields_same(a, b, everything, ctx="sigma changed behind a chained batch, step %d" % a.istep)
     assert_fields_same(a, o, ctx="chained batches / oracle, step %d" % a.istep)
     assert a.get_counter("tm_steps") >= 100 and b.get_counter("tm_steps") == 0
+    # the pieces of a strip call (vof_step_tm_piece) on a handle that is ahead: head, one middle step, the last step
+    run((16,))
+    for piece in (0, 1, 2):
+        a.step_tm_piece(piece)
+    for e in (b, o):
+        e.step(2)
+    assert_fields_same(a, b, everything, ctx="strip pieces behind a chained batch, step %d" % a.istep)
+    assert_fields_same(a, o, ctx="strip pieces behind a chained batch / oracle, step %d" % a.istep)
 
 
 @pytest.mark.gpu
