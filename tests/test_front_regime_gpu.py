@@ -156,7 +156,8 @@ def test_batch_forms_are_timed_again_and_switching_changes_no_value(hip_api):
 def test_batch_form_follows_a_rule_on_the_state(hip_api):
     """The default (fuse_tm = -1): which batch form a large fp64 full domain runs is a function of the state -- the share
     of exact-zero cells of F when the handle first batches steps -- not of a stopwatch: two fresh handles agree, a
-    dam-break (5/6 gas) runs k_tm + k_jacobi_pair, a rising bubble (2 % gas) the chains, and where the rule does not
+    dam-break (5/6 gas) runs k_tm + k_jacobi_pair, a rising bubble (2 % gas) the chains -- up to 20 M cells; beyond, the pair
+    kernels whatever the grid holds --, and where the rule does not
     apply (fp32, small grids) the counter says so.  Replacing F makes the handle look again."""
     n = 4096
     a = engine(hip_api, n, n, "f64", "f32", ic=1)
@@ -173,6 +174,10 @@ def test_batch_form_follows_a_rule_on_the_state(hip_api):
     assert a.get_counter("tm_choice") == 0 and a.get_param("gas_share") < 0.05
     assert a.get_counter("halves_steps") >= 16
     a.close()
+    g = engine(hip_api, 5120, 5120, "f64", "f32", ic=2)   # from 20 M cells on the pair kernels win whatever the grid holds
+    g.step(36)
+    assert g.get_counter("tm_choice") == 1 and g.get_param("gas_share") < 0.05 and g.get_counter("tm_steps") >= 32
+    g.close()
     c = engine(hip_api, n, n, "f32", "f32", ic=1)
     d = engine(hip_api, 2048, 2048, "f64", "f32", ic=1)
     for e in (c, d):
