@@ -119,6 +119,10 @@ inline bool buffer_stores_ok(const vof2d_ctx* h) {
 }
 
 // ------------------------------------------------------------------ launches
+// From this many cells on a full domain runs the pair kernels whatever it holds and in fp32 too (the rule of vof_step,
+// runtime/schedule.h): bubble fp64 5120^2 0.78-0.83 against 0.89-0.92 ms/step for the chains, 8192^2 1.67-1.71 / 2.17-2.20;
+// dam-break fp32 6144^2 0.50-0.51 / 0.69, 8192^2 0.83 / 1.18 (4096^2 fp32: 0.354 / 0.334 -- below it fp32 keeps the chains)
+constexpr long kTmAlwaysCells = 20000000L;
 constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe
 enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
                 kRhs, kOther, kTransport, kJacobiPair, kTM, kTMUV, NKERNELS };
@@ -242,9 +246,10 @@ struct L {
   // k_jacobi_pair (two five-sweep launches as one, kernels/jacobi_pair.h): square cells, ten sweeps per step at least
   static bool jacobi_pair_ok(vof2d_ctx* h) {
     const Consts<T> cc = C(h);
-    // (fp32: slower than two k_jacobi_tb launches -- 4096^2 k_tm form 0.3615 -> 0.3815 ms/step: those are issue-bound and the
-    // pairs add a fifth of redundant stage-rows; knob value 2 forces the pairs there too, for the tests)
-    return (h->jpair > 1 || (h->jpair == 1 && sizeof(T) == 8)) && cc.dxi2 == cc.dyi2 && !h->tb_general && h->tb >= 5 &&
+    // (fp32 below 20 M cells: slower than two k_jacobi_tb launches -- 4096^2 k_tm form 0.333 -> 0.354 ms/step; knob value 2 forces
+    // the pairs there too, for the tests)
+    const bool big = (long)(h->g.ihi - h->g.ilo + 1) * h->g.ny >= kTmAlwaysCells && h->g.wall_lo && h->g.wall_hi;   // (fp32: full domains from 20 M cells on)
+    return (h->jpair > 1 || (h->jpair == 1 && (sizeof(T) == 8 || big))) && cc.dxi2 == cc.dyi2 && !h->tb_general && h->tb >= 5 &&
            h->d.jacobi_iters % 10 == 0;
   }
   // Columns per lane of the pair kernels: 2, or -- fp32, knob "pair_vec4" -- 4: a lane then moves the 16 bytes per row the fp64

@@ -207,12 +207,10 @@ inline bool tm_eligible(const vof2d_ctx* h) {
 // liquid --, 4096^2 fp32 0.364 / 0.337 / 0.361, 3072^2 0.351 / 0.346 / 0.346, 2048^2 0.168 / - / 0.188) -- the form is chosen by
 // a rule on the state (fuse_tm = -1, the default: decide_batch_form_by_rule) or, for exploration, by timing both (fuse_tm = -2).
 constexpr double kTmGasShare = 0.5;   // k_tm from this share of exact-zero cells of F on
-// ... and on grids of this many cells whatever they hold: rising bubble (2 % gas), k_tm + k_jacobi_pair against the chains,
-// ms/step: 3072^2 0.401-0.443 / 0.393-0.447, 4096^2 0.584-0.639 / 0.605-0.637 (ties), 5120^2 0.78-0.83 / 0.89-0.92,
-// 6144^2 1.03-1.10 / 1.27-1.31, 8192^2 1.67-1.71 / 2.17-2.20 (profiles/r05_forms_ab_final.txt)
-constexpr long kTmAlwaysCells = 20000000L;
+// ... and on grids of kTmAlwaysCells and more whatever they hold, in fp32 too (runtime/launches.h)
 inline bool tm_size_ok(const vof2d_ctx* h) {
-  return tm_eligible(h) && h->d.dtype == VOF_F64 && (long)h->g.nx * h->g.ny >= 6000000L && h->g.nx >= 2048;   // (the sizes that run chains: below, neither form pays)
+  const long cells = (long)h->g.nx * h->g.ny;
+  return tm_eligible(h) && (h->d.dtype == VOF_F64 || cells >= kTmAlwaysCells) && cells >= 6000000L && h->g.nx >= 2048;   // (the sizes that run chains: below, neither form pays)
 }
 inline bool tm_by_rule(const vof2d_ctx* h) { return h->fuse_tm == -1 && tm_size_ok(h); }
 inline bool tm_auto(const vof2d_ctx* h) { return h->fuse_tm == -2 && tm_size_ok(h); }

@@ -178,6 +178,19 @@ def test_batch_form_follows_a_rule_on_the_state(hip_api):
     g.step(36)
     assert g.get_counter("tm_choice") == 1 and g.get_param("gas_share") < 0.05 and g.get_counter("tm_steps") >= 32
     g.close()
+    # ... in fp32 too (below 20 M cells fp32 keeps the chains), value for value what the chains give
+    g = engine(hip_api, 5120, 5120, "f32", "f32", ic=1)
+    k = engine(hip_api, 5120, 5120, "f32", "f32", ic=1)
+    k.set_param("fuse_tm", 0)
+    for e in (g, k):
+        e.step(44)
+    assert g.get_counter("tm_choice") == 1 and g.get_counter("tm_steps") >= 40 and g.get_counter("pair_launches") >= 40
+    assert k.get_counter("tm_steps") == 0 and k.get_counter("halves_steps") >= 32
+    for f in STATE:
+        x, y = g.get(f), k.get(f)
+        assert same(x, y), "5120^2 fp32, pair kernels by the rule against the chains: %s" % diff_report(x, y, f)
+        del x, y
+    g.close(); k.close()
     c = engine(hip_api, n, n, "f32", "f32", ic=1)
     d = engine(hip_api, 2048, 2048, "f64", "f32", ic=1)
     for e in (c, d):
