@@ -210,7 +210,9 @@ constexpr double kTmGasShare = 0.5;   // k_tm from this share of exact-zero cell
 // ... and on grids of kTmAlwaysCells and more whatever they hold, in fp32 too (runtime/launches.h)
 inline bool tm_size_ok(const vof2d_ctx* h) {
   const long cells = (long)h->g.nx * h->g.ny;
-  return tm_eligible(h) && (h->d.dtype == VOF_F64 || cells >= kTmAlwaysCells) && cells >= 6000000L && h->g.nx >= 2048;   // (the sizes that run chains: below, neither form pays)
+  // (fp64 dam-break, k_tm + k_jacobi_pair against the plain sequence, ms/step: 1024^2 0.131 / 0.087, 1536^2 0.143 / 0.124, 2048^2 0.160 / 0.171,
+  //  2560^2 0.217 / 0.240, 3072^2 0.269 / 0.339: from 4 M cells on)
+  return tm_eligible(h) && (h->d.dtype == VOF_F64 || cells >= kTmAlwaysCells) && cells >= 4000000L && h->g.nx >= 2048;
 }
 inline bool tm_by_rule(const vof2d_ctx* h) { return h->fuse_tm == -1 && tm_size_ok(h); }
 inline bool tm_auto(const vof2d_ctx* h) { return h->fuse_tm == -2 && tm_size_ok(h); }

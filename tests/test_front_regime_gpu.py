@@ -192,7 +192,7 @@ def test_batch_form_follows_a_rule_on_the_state(hip_api):
         del x, y
     g.close(); k.close()
     c = engine(hip_api, n, n, "f32", "f32", ic=1)
-    d = engine(hip_api, 2048, 2048, "f64", "f32", ic=1)
+    d = engine(hip_api, 1536, 1536, "f64", "f32", ic=1)   # (below 4 M cells neither form pays)
     for e in (c, d):
         e.step(20)
         assert e.get_counter("tm_choice") == -1 and e.get_counter("tm_steps") == 0
