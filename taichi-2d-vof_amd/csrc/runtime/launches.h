@@ -119,9 +119,9 @@ inline bool buffer_stores_ok(const vof2d_ctx* h) {
 }
 
 // ------------------------------------------------------------------ launches
-// From this many cells on a full domain runs the pair kernels whatever it holds and in fp32 too (the rule of vof_step,
-// runtime/schedule.h): bubble fp64 5120^2 0.78-0.83 against 0.89-0.92 ms/step for the chains, 8192^2 1.67-1.71 / 2.17-2.20;
-// dam-break fp32 6144^2 0.50-0.51 / 0.69, 8192^2 0.83 / 1.18 (4096^2 fp32: 0.354 / 0.334 -- below it fp32 keeps the chains)
+// From this many cells on a full domain runs the pair kernels whatever it holds (the rule of vof_step, runtime/schedule.h):
+// bubble (2 % gas) fp64 4096^2 0.58-0.64 against 0.61-0.64 ms/step for the chains (a tie), 5120^2 0.78-0.83 / 0.89-0.92,
+// 8192^2 1.67-1.71 / 2.17-2.20; fp32 3072^2 0.257-0.280 / 0.252-0.265, 4096^2 0.366-0.403 / 0.371-0.396
 constexpr long kTmAlwaysCells = 20000000L;
 constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe
 enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
@@ -246,10 +246,9 @@ struct L {
   // k_jacobi_pair (two five-sweep launches as one, kernels/jacobi_pair.h): square cells, ten sweeps per step at least
   static bool jacobi_pair_ok(vof2d_ctx* h) {
     const Consts<T> cc = C(h);
-    // (fp32 below 20 M cells: slower than two k_jacobi_tb launches -- 4096^2 k_tm form 0.333 -> 0.354 ms/step; knob value 2 forces
-    // the pairs there too, for the tests)
-    const bool big = (long)(h->g.ihi - h->g.ilo + 1) * h->g.ny >= kTmAlwaysCells && h->g.wall_lo && h->g.wall_hi;   // (fp32: full domains from 20 M cells on)
-    return (h->jpair > 1 || (h->jpair == 1 && (sizeof(T) == 8 || big))) && cc.dxi2 == cc.dyi2 && !h->tb_general && h->tb >= 5 &&
+    // (both precisions since the chained batches: 4096^2 fp32 dam-break 0.268 ms/step in the k_tm form with the pairs, 0.343 in
+    //  chains; knob values 1 and 2 are the same now)
+    return h->jpair >= 1 && cc.dxi2 == cc.dyi2 && !h->tb_general && h->tb >= 5 &&
            h->d.jacobi_iters % 10 == 0;
   }
   // Columns per lane of the pair kernels: 2, or -- fp32, knob "pair_vec4" -- 4: a lane then moves the 16 bytes per row the fp64

@@ -207,12 +207,13 @@ inline bool tm_eligible(const vof2d_ctx* h) {
 // liquid --, 4096^2 fp32 0.364 / 0.337 / 0.361, 3072^2 0.351 / 0.346 / 0.346, 2048^2 0.168 / - / 0.188) -- the form is chosen by
 // a rule on the state (fuse_tm = -1, the default: decide_batch_form_by_rule) or, for exploration, by timing both (fuse_tm = -2).
 constexpr double kTmGasShare = 0.5;   // k_tm from this share of exact-zero cells of F on
-// ... and on grids of kTmAlwaysCells and more whatever they hold, in fp32 too (runtime/launches.h)
+// ... and on grids of kTmAlwaysCells and more whatever they hold (runtime/launches.h); both precisions
 inline bool tm_size_ok(const vof2d_ctx* h) {
   const long cells = (long)h->g.nx * h->g.ny;
   // (fp64 dam-break, k_tm + k_jacobi_pair against the plain sequence, ms/step: 1024^2 0.131 / 0.087, 1536^2 0.143 / 0.124, 2048^2 0.160 / 0.171,
   //  2560^2 0.217 / 0.240, 3072^2 0.269 / 0.339: from 4 M cells on)
-  return tm_eligible(h) && (h->d.dtype == VOF_F64 || cells >= kTmAlwaysCells) && cells >= 4000000L && h->g.nx >= 2048;
+  //  fp32: 2048^2 0.121-0.133 / 0.123-0.142, 2560^2 0.142-0.157 / 0.171-0.176, 3072^2 0.188 / 0.23, 4096^2 0.268 / 0.343)
+  return tm_eligible(h) && cells >= 4000000L && h->g.nx >= 2048;
 }
 inline bool tm_by_rule(const vof2d_ctx* h) { return h->fuse_tm == -1 && tm_size_ok(h); }
 inline bool tm_auto(const vof2d_ctx* h) { return h->fuse_tm == -2 && tm_size_ok(h); }

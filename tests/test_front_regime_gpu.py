@@ -178,7 +178,7 @@ def test_batch_form_follows_a_rule_on_the_state(hip_api):
     g.step(36)
     assert g.get_counter("tm_choice") == 1 and g.get_param("gas_share") < 0.05 and g.get_counter("tm_steps") >= 32
     g.close()
-    # ... in fp32 too (below 20 M cells fp32 keeps the chains), value for value what the chains give
+    # ... in fp32 too, value for value what the chains give
     g = engine(hip_api, 5120, 5120, "f32", "f32", ic=1)
     k = engine(hip_api, 5120, 5120, "f32", "f32", ic=1)
     k.set_param("fuse_tm", 0)
@@ -191,7 +191,11 @@ def test_batch_form_follows_a_rule_on_the_state(hip_api):
         assert same(x, y), "5120^2 fp32, pair kernels by the rule against the chains: %s" % diff_report(x, y, f)
         del x, y
     g.close(); k.close()
-    c = engine(hip_api, n, n, "f32", "f32", ic=1)
+    c = engine(hip_api, n, n, "f32", "f32", ic=1)          # (the same rule in fp32)
+    c.step(40)
+    assert c.get_counter("tm_choice") == 1 and c.get_counter("tm_steps") >= 32
+    c.close()
+    c = engine(hip_api, 1536, 1536, "f32", "f32", ic=1)
     d = engine(hip_api, 1536, 1536, "f64", "f32", ic=1)   # (below 4 M cells neither form pays)
     for e in (c, d):
         e.step(20)
