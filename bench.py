@@ -695,6 +695,7 @@ def main():
     sweep_bytes = 3 * esz * comp_rows * ny          # read p, read rhs, write p' per computed cell
     tb = int(eng.get_param("jacobi_tb"))
     nt = max(2 * tb, a.jacobi_sweeps_timed // (2 * tb) * 2 * tb)
+    eng.set_param("solve_pairs", 0)            # (this record is k_jacobi_tb's: five sweeps per launch, not the pair kernel's ten)
     ms_sweep_tb = eng.time_jacobi(nt)
     eng.set_param("jacobi_tb", 1)
     ms_sweep_1 = eng.time_jacobi(max(2, a.jacobi_sweeps_timed // 2 * 2))

@@ -127,8 +127,8 @@ int vof_set_istep(vof2d_handle h, int64_t istep);
 /* Extension (not in the reference, whose :521-522 runs a fixed 10 sweeps; SURVEY 8f-1, BASELINE
  * configs[1] "Jacobi Poisson to 1e-6 residual"): rhs once, then Jacobi sweeps (:258-266) until the
  * residual of the last sweep of a batch is <= tol, checked every check_every sweeps, at most
- * max_iters sweeps.  The sweeps of a batch run fused (five per launch) and the last launch reduces
- * the two norms itself.
+ * max_iters sweeps.  The sweeps of a batch run fused (five per launch; ten -- k_jacobi_pair -- on square cells from 4 M
+ * cells on) and the last launch reduces the two norms itself.
  *   VOF_RESID_ABS:  residual = max|p_new - p|                                  over owned rows
  *   VOF_RESID_REL:  residual = max|p_new - p| / max(max|p_new|, VOF_RESID_TINY)   
  * A non-finite update (a diverged field) reads as residual = +inf and ends the solve; that is the only

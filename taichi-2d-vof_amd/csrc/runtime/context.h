@@ -186,6 +186,7 @@ struct vof2d_ctx {
   int64_t tm_chained = 0;    // k_tm batches that started without a k_momentum launch (counter "tm_chained_batches")
   int jpair = 1;             // knob "jacobi_pair": the k_tm batch graphs run each two five-sweep launches as one k_jacobi_pair launch
   int jpair_rows = 0;        // rows per pair chunk (0 = one residency round of pairs)
+  int solve_pairs = -1;      // knob "solve_pairs": jacobi_n (the residual-terminated solve, the verbs, the last step of a strip call) runs ten sweeps per launch as k_jacobi_pair where it applies (-1: from 4 M cells on, solve_pairs_on)
   // knobs "pair_slow10", "tb_slow10": what the planner takes a row of a reported band to cost, in tenths of an ordinary row.
   // k_jacobi_pair, 4096^2 dam-break, us per launch in steps 301-350 / ms per step over steps 61-660: 20 146.6 / 0.4454, 26 132.0 / 0.4355,
   // 32 127.2 / 0.4312, 40 128.4 / 0.4328, 50 129.8 / 0.4338 (the cold tier costs more against the FAST sub-iterations than it did

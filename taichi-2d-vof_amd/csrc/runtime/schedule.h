@@ -75,6 +75,11 @@ void copy_interior(vof2d_ctx* h, int src, int dst) {
 // cells keep their set_BC values like the reference's copy-back loop :265-266).  Sweeps are grouped
 // into launches of h->tb fused sweeps (k_jacobi_tb); the remainder and the residual variant use the
 // single-sweep kernel.
+// knob "solve_pairs": -1 (default) from 4 M stored cells on -- us per sweep, back to back, five per launch / ten per launch:
+// 1024^2 3.10 / 3.41 (the solve of BASELINE configs[1]: 0.93 / 1.05 s), 2048^2 5.99 / 5.16, 4096^2 18.3 / 11.6
+inline bool solve_pairs_on(const vof2d_ctx* h) {
+  return h->solve_pairs > 0 || (h->solve_pairs < 0 && (long)(h->d.row_hi - h->d.row_lo + 1) * h->g.ny >= 4000000L);
+}
 template <typename T>
 void jacobi_n(vof2d_ctx* h, int n, bool resid_last, int adapt_par = -1) {
   if (n <= 0) return;
@@ -88,7 +93,10 @@ void jacobi_n(vof2d_ctx* h, int n, bool resid_last, int adapt_par = -1) {
   const int last = !resid_last ? 0 : ((tb >= 5 && n >= 5) ? 5 : ((tb >= 2 && n >= 2) ? 2 : 1));
   left -= last;
   while (left > 0) {
-    if (tb >= 5 && left >= 5) { L<T>::template jacobi_tb<5>(h, cur, oth, adapt_par); left -= 5; }
+    // (ten sweeps per launch where the pair kernel applies and no work plan is asked for: the residual-terminated solve,
+    //  the verbs, the last step of a strip call)
+    if (solve_pairs_on(h) && adapt_par < 0 && left >= 10 && L<T>::jacobi_pair_ok(h)) { L<T>::jacobi_pair(h, cur, oth, -1); left -= 10; }
+    else if (tb >= 5 && left >= 5) { L<T>::template jacobi_tb<5>(h, cur, oth, adapt_par); left -= 5; }
     else if (tb >= 2 && left >= 2) { L<T>::template jacobi_tb<2>(h, cur, oth); left -= 2; }
     else { L<T>::template jacobi<false>(h, cur, oth); left -= 1; }
     flip();

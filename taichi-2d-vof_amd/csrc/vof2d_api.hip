@@ -724,7 +724,7 @@ int vof_set_param(vof2d_handle h, const char* name, double value) {
             : !strcmp(name, "momentum_rows") ? &h->mom_rows : !strcmp(name, "fctx_rows") ? &h->fctx_rows
             : !strcmp(name, "fctx_corr_rows") ? &h->fctx_corr_rows : !strcmp(name, "band_rows") ? &h->band_rows
             : !strcmp(name, "rows_per_wave") ? &h->rows_override : !strcmp(name, "fuse_transport") ? &h->fuse_transport
-            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : !strcmp(name, "jacobi_pair") ? &h->jpair : !strcmp(name, "jacobi_pair_rows") ? &h->jpair_rows : !strcmp(name, "pair_vec4") ? &h->pair_vec4 : !strcmp(name, "pair_slow10") ? &h->pair_slow10 : !strcmp(name, "tb_slow10") ? &h->tb_slow10 : !strcmp(name, "tune_period") ? &h->tune_period : nullptr;
+            : !strcmp(name, "virtual_ghosts") ? &h->virtual_ghosts : !strcmp(name, "buffer_stores") ? &h->buf_stores : !strcmp(name, "overlap_halves") ? &h->halves : !strcmp(name, "batch_steps") ? &h->step_batch[0] : !strcmp(name, "fuse_tm") ? &h->fuse_tm : !strcmp(name, "tm_rows") ? &h->tm_rows : !strcmp(name, "jacobi_pair") ? &h->jpair : !strcmp(name, "jacobi_pair_rows") ? &h->jpair_rows : !strcmp(name, "pair_vec4") ? &h->pair_vec4 : !strcmp(name, "pair_slow10") ? &h->pair_slow10 : !strcmp(name, "solve_pairs") ? &h->solve_pairs : !strcmp(name, "tb_slow10") ? &h->tb_slow10 : !strcmp(name, "tune_period") ? &h->tune_period : nullptr;
   if (knob) {
     *knob = (int)value;
     if (knob == &h->band_rows && *knob < 1) *knob = 1;
