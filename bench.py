@@ -85,11 +85,20 @@ def parse():
     ap.add_argument("--no-balance", action="store_true",
                     help="N > 1 (native exchange): keep equal strips instead of re-cutting them by the measured cost of "
                          "each rank's rows (strips.balanced_partition)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="N > 1 REHEARSAL on one GPU: every rank opens device 0.  RCCL refuses to form a communicator of two ranks "
+                         "on one device, so the native attempt ends at vof_comm_init (after the rendezvous) and the halos travel by "
+                         "the second carrier over gloo, staged through host memory (StripSolver.stage_host): the launcher, the "
+                         "supervisor, the rendezvous, the cost re-cut and the assembly of the N > 1 line run on real HIP handles.  "
+                         "The rate it prints is of N processes sharing one GPU -- a plumbing check, not a scaling figure")
+    ap.add_argument("--digest", action="store_true",
+                    help="N > 1: gather F, u, v, p on rank 0 after the timed steps and put their SHA-256 (and the step count) into the "
+                         "line (`fields_sha256`), for comparison with a single-domain run of the same number of steps")
     ap.add_argument("--overlap", type=int, default=5, choices=[0, 1, 3, 4, 5],
                     help="N > 1: 0 = one exchange after the step, 1 = each field as soon as it is final, "
                          "3 = p, u, v together after the first sweep, 4 = fused transport "
                          "kernel on the edge bands, all four fields in one group under the transport of the other rows, "
-                         "5 (default; fp64: fp32 runs 4) = the pair kernels of the single GPU -- k_jacobi_pair and k_tm --, F, u*, "
+                         "5 (default, both precisions) = the pair kernels of the single GPU -- k_jacobi_pair and k_tm --, F, u*, "
                          "v*, rhs, p exchanged once per step (vof_step_exchange)")
     return ap.parse_args()
 
@@ -510,6 +519,60 @@ def roofline_of_the_kept_form(run_kernels, classic, traffic_tm, note_tm, nprof, 
     return out
 
 
+def balance_strips(a, comm, solver, make_solver, rank, world, nx):
+    """Strips do not cost the same: rows of gas take the sweeps' zero shortcuts, the liquid and the interface do not (and
+    GPUs differ a little).  Time each rank's strip on the equal partition, re-cut the rows so that every rank gets the
+    same share of the cost, and start again from the initial condition.  Results do not depend on the partition.
+    The probe times the rank's own kernels on VALID data (the kernels are data dependent: zero shortcuts, division
+    tiers -- stale halos would feed them garbage rows): one kernel-only step, timed on the device, then a full halo
+    exchange before the next one (a deep halo covers exactly one step).  Waiting for neighbours is not in the figure, or
+    every rank would read the slowest rank's time.  A failure on one rank is agreed on before anybody changes partition.
+    Either carrier (comm: an EnvComm beside the library's own RCCL communicator, or a TorchComm).  Returns the solver to
+    time -- a new one, from the initial condition again."""
+    if not ((world > 1 or os.environ.get("VOF2D_BENCH_TEST_BALANCE")) and not a.no_balance):   # (env: self-test of this block with one rank)
+        return solver
+    from vof2d.strips import balanced_partition
+    parts = solver.parts
+    for _round in range(2):    # the second cut corrects what the piecewise-uniform cost model of the first missed
+        cost, failed = 0.0, 0.0
+        try:
+            with _StdoutToStderr():
+                samples = []
+                for _k in range(10):
+                    solver.eng.timer_start()
+                    solver.eng.step(1)
+                    samples.append(solver.eng.timer_stop())   # ms of this rank's stream
+                    solver.exchange()
+                cost = sum(samples[2:]) / len(samples[2:])
+        except Exception as exc:
+            print("[bench] rank %d: cost probe failed (%r)" % (rank, exc), file=sys.stderr)
+            failed = 1.0
+        failed = comm.allreduce_max(failed, solver.eng)     # every rank leaves the block together
+        new_parts = None
+        if not failed:
+            costs = comm.gather_object(cost)
+            decision = None
+            if rank == 0:
+                try:
+                    if max(costs) > (1.015, 1.03)[_round] * sum(costs) / len(costs):
+                        decision = balanced_partition(nx, parts, costs, min_rows=solver.halo)
+                    # else: balanced within 1.5 % (3 % after one cut: chunk lengths quantise a strip's cost)
+                except Exception as exc:      # keep every rank on the same partition whatever happens here
+                    print("[bench] cost balancing failed (%r): keeping the strips" % (exc,), file=sys.stderr)
+            new_parts = comm.broadcast_object(decision)
+        solver.barrier()
+        with _StdoutToStderr():
+            solver.close()
+        if new_parts is not None:
+            parts = [tuple(pr) for pr in new_parts]
+        # (a new strip handle and with it -- native carrier -- a new RCCL communicator: ncclCommInitRank on one node takes
+        # about a second, at most twice per run, well inside the supervisor's limit)
+        solver = make_solver(parts)       # from the initial condition again
+        if new_parts is None:
+            break
+    return solver
+
+
 # --------------------------------------------------------------------------------------------------
 def main():
     a = parse()
@@ -520,6 +583,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.same_device:
+        local = 0               # (the rehearsal: every rank on the one GPU there is)
     if a.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d (start `python bench.py --gpus N` without a launcher, "
                          "or with python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
@@ -530,7 +595,7 @@ def main():
         from vof2d.comms import EnvComm
         comm = EnvComm(rank, world, local)
         token = comm.broadcast_object({"token": os.getpid()} if rank == 0 else None)
-        got = comm.gather_object({"rank": rank, "local_rank": local, "world": world, "token": token["token"],
+        got = comm.gather_object({"rank": rank, "local_rank": local, "world": world, "token": token["token"], "same_device": bool(a.same_device),
                                   "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))})
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": got}), flush=True)
@@ -550,8 +615,6 @@ def main():
         return a.dt if a.dt > 0 else (4e-6 if n <= 4096 else 1e-6)
     dt = stable_dt(max(nx, ny))
 
-    if a.overlap == 5 and a.dtype != "f64":
-        a.overlap = 4          # (the pair kernels pay in fp64: DESIGN.md 3.5 / 3.6)
     dist_path = world > 1 or a.force_dist
     comm = None
     exchange = "none"
@@ -582,56 +645,7 @@ def main():
                     return StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local, parts=parts,
                                        jacobi_iters=a.jacobi_iters, comm=comm, exchange="native" if world > 1 else "auto", dt=dt)
             solver = make_solver()
-            parts = solver.parts
-            if (world > 1 or os.environ.get("VOF2D_BENCH_TEST_BALANCE")) and not a.no_balance:   # (env: self-test of this block with one rank)
-                # Strips do not cost the same: rows of gas take the sweeps' zero shortcuts, the liquid and
-                # the interface do not (and GPUs differ a little).  Time each rank's strip on the equal
-                # partition, re-cut the rows so that every rank gets the same share of the cost, and
-                # start again from the initial condition.  Results do not depend on the partition.
-                # The probe times the rank's own kernels on VALID data (the kernels are data dependent: zero
-                # shortcuts, division tiers -- stale halos would feed them garbage rows): one kernel-only
-                # step, timed on the device, then a full halo exchange before the next one (a deep halo
-                # covers exactly one step).  Waiting for neighbours is not in the figure, or every rank
-                # would read the slowest rank's time.  A failure on one rank is agreed on before anybody
-                # changes partition.
-                from vof2d.strips import balanced_partition
-                for _round in range(2):    # the second cut corrects what the piecewise-uniform cost model of the first missed
-                    cost, failed = 0.0, 0.0
-                    try:
-                        with _StdoutToStderr():
-                            samples = []
-                            for _k in range(10):
-                                solver.eng.timer_start()
-                                solver.eng.step(1)
-                                samples.append(solver.eng.timer_stop())   # ms of this rank's stream
-                                solver.exchange()
-                            cost = sum(samples[2:]) / len(samples[2:])
-                    except Exception as exc:
-                        print("[bench] rank %d: cost probe failed (%r)" % (rank, exc), file=sys.stderr)
-                        failed = 1.0
-                    failed = comm.allreduce_max(failed, solver.eng)     # every rank leaves the block together
-                    new_parts = None
-                    if not failed:
-                        costs = comm.gather_object(cost)
-                        decision = None
-                        if rank == 0:
-                            try:
-                                if max(costs) > (1.015, 1.03)[_round] * sum(costs) / len(costs):
-                                    decision = balanced_partition(nx, parts, costs, min_rows=solver.halo)
-                                # else: balanced within 1.5 % (3 % after one cut: chunk lengths quantise a strip's cost)
-                            except Exception as exc:      # keep every rank on the same partition whatever happens here
-                                print("[bench] cost balancing failed (%r): keeping the strips" % (exc,), file=sys.stderr)
-                        new_parts = comm.broadcast_object(decision)
-                    solver.barrier()
-                    with _StdoutToStderr():
-                        solver.close()
-                    if new_parts is not None:
-                        parts = [tuple(pr) for pr in new_parts]
-                    # (a new strip handle and with it a new RCCL communicator: ncclCommInitRank on one node takes
-                    # about a second, at most twice per run, well inside the supervisor's limit)
-                    solver = make_solver(parts)       # from the initial condition again
-                    if new_parts is None:
-                        break
+            solver = balance_strips(a, comm, solver, make_solver, rank, world, nx)
             native_ok = True
         except Exception as exc:   # e.g. no loadable RCCL: symmetric on all ranks -> the torch carrier
             print("[bench] native RCCL exchange unavailable (%r); falling back to torch.distributed" % (exc,), file=sys.stderr)
@@ -662,27 +676,49 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        # the second carrier: torch.distributed P2P.  Backend "nccl" (= RCCL) between GPUs; "gloo" with the rows staged through
+        # host memory for the one-GPU rehearsal (--same-device), where two ranks share a device and RCCL cannot be used at all
+        gloo = bool(a.same_device)
         torch.cuda.set_device(local)
+        ov = a.overlap if a.overlap == 5 else bool(a.overlap)     # (5: the library's pair kernels piece by piece, StripSolver._step_pieces)
         with _StdoutToStderr():
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            solver = StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local,
-                                 jacobi_iters=a.jacobi_iters, exchange="torch", dt=dt)
+            if gloo:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+            def make_solver_t(parts=None):
+                return StripSolver(nx, ny, a.dtype, ic=a.ic, rank=rank, world=world, device=local, parts=parts,
+                                   jacobi_iters=a.jacobi_iters, exchange="torch", dt=dt)
+            solver = make_solver_t()
+            if world > 1:
+                solver = balance_strips(a, solver.comm, solver, make_solver_t, rank, world, nx)
             eng = solver.eng
-            solver.step(a.warmup, overlap=bool(a.overlap))
+            solver.step(a.warmup, overlap=ov)
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        solver.step(a.steps, overlap=bool(a.overlap))
+        solver.step(a.steps, overlap=ov)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        exchange = "torch" if world > 1 else "none"
+        exchange = ("torch/gloo (host-staged)" if gloo else "torch") if world > 1 else "none"
 
+    digests = None
+    if dist_path and a.digest:
+        import hashlib
+        eng.sync()          # (before the Jacobi timing below advances p)
+        got = {f: solver.gather(f) for f in ("F", "u", "v", "p")}       # (every rank takes part; rank 0 holds the fields)
+        if rank == 0:
+            digests = {f: hashlib.sha256(got[f].tobytes()).hexdigest() for f in got}
+            digests["istep"] = int(eng.istep)
+            digests["shape"] = list(got["F"].shape)
+        del got
     # Jacobi kernels.
     # (1) the north-star kernel: k_jacobi, one sweep per launch, 3 array passes, HBM-bound.  Timed
     #     live with one HIP event pair on the stream the kernels are launched on, around
@@ -789,7 +825,7 @@ def main():
     except Exception:
         one_kernel_transport = False
     ARRAYS_PER_STEP = ARRAYS_PER_STEP_FULL if one_kernel_transport else ARRAYS_PER_STEP_STRIP
-    if dist_path and exchange == "native" and a.overlap == 5:
+    if dist_path and world > 1 and a.overlap == 5:
         ARRAYS_PER_STEP = 11        # k_jacobi_pair 3 + k_tm 8 per middle step (the head and the tail of a call: once per call)
     # What the step AS THE HANDLE RAN IT has to move, by SURVEY 8d's rule applied to its own kernel list (every distinct
     # array a kernel reads or writes, once, times its launches per step, from the in-situ profile of the kept form):
@@ -844,6 +880,9 @@ def main():
                 "exchange_graph": (eng.comm_info()[1] == 1) if exchange == "native" else None,
                 "exchange_graph_steps_in_timed_region": graph_steps,
                 "multi_gpu_hardware_verified": False if world > 1 else None,
+                # the one-GPU rehearsal of the N > 1 path (--same-device): every rank on device 0, halos over gloo through host
+                # memory -- the line's rate is of N processes sharing one GPU and says nothing about scaling
+                "same_device_rehearsal": bool(a.same_device) if dist_path else None,
                 "arrays_per_cell_update": round(own_passes, 3),
                 "bytes_per_cell_update_algorithmic": round(own_passes * esz, 2),
                 "arrays_per_cell_update_four_kernel_schedule": ARRAYS_PER_STEP,
@@ -875,6 +914,7 @@ def main():
             # stop; reads a few us high behind a long-tailed predecessor -- rocprofv3, profiles/, is the reference)
             "step_kernels": step_kernels,
             "strong_scaling_reference_n1": ref8192,
+            "fields_sha256": digests,
             "speedup_same_grid": speedup,
             "step_hbm_gbs_algorithmic": own_passes * esz * nx * ny * a.steps / elapsed / 1e9,
             "step_frac_of_peak_algorithmic": fractions["own_kernel_list"],

@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define VOF_ABI_VERSION 1
+/* 2: VOF_HALO_ROWS grew from jacobi_iters + 6 to jacobi_iters + 8 (overlap mode 5: the momentum march of k_tm reads F, u*, v* one
+ * stencil further than the four-kernel step): strips and checkpoints laid out with the old macro are refused by vof_create instead of
+ * failing later in vof_comm_init. */
+#define VOF_ABI_VERSION 2
 
 /* dtype of every field (2dvof.py:9 default_fp) */
 #define VOF_F64 0
@@ -46,10 +49,10 @@ extern "C" {
 #define VOF_ESTATE (-4)  /* call not valid in the handle's current state */
 
 /* width (rows) of the per-step deep halo a strip needs on each interior side.
- * Dependency radius of one step in i (DESIGN.md "strips"): normals 1 +
- * curvature 1 + predictor 1 + n Jacobi sweeps + update_uv 1 + fct_x_sweep 2
- * (velocity) = n + 5 on the low side, rhs 1 + n + fct_x_sweep 3 + ... = n + 5
- * on the high side; one spare row is allocated. */
+ * Dependency radius of one step in i: modes 0-4 (the four-kernel step) normals 1 +
+ * curvature 1 + predictor 1 + n Jacobi sweeps + update_uv 1 + fct_x_sweep 2 (velocity) = n + 5 on the low side,
+ * rhs 1 + n + fct_x_sweep 3 + ... = n + 5 on the high side; overlap mode 5 (the pair kernels: the momentum march of
+ * k_tm reads F'', u*, v* one stencil further) n + 7; one spare row is allocated.  ABI version 1 had n + 6. */
 #define VOF_HALO_ROWS(jacobi_iters) ((jacobi_iters) + 8)
 
 typedef struct vof2d_desc {
@@ -107,7 +110,8 @@ int vof_post_process_f(vof2d_handle h);             /* :452-455 */
  * five-sweep k_jacobi_tb, k_transport -- replayed from a hipGraph (the first step after set_init_F /
  * set_field / a single verb runs eagerly with the intermediate boundary launches the reference's
  * :518 / :525 stand for; steady-state steps are replayed in batches of 16 / 8 / 2 per graph launch, as chains of
- * launches on row blocks); large fp64 grids that are mostly gas run two launches per step --
+ * launches on row blocks); large grids (either precision: from 4 M cells on where at least half of the cells are
+ * gas, from 20 M cells on whatever they hold -- a rule on the state, looked at once per handle and initial state) run two launches per step --
  * k_jacobi_pair (ten sweeps) and k_tm (the step's transport + the next step's momentum), DESIGN.md 3.5 / 3.6 -- in
  * batches of 32 / 8 / 2 that chain.  Whatever the form, F u v p u_star v_star rhs read back after n steps are the
  * reference's after n steps.  rho / nu / mx / my / kappa scratch is not materialised (the k_tm form uses mx, my,

@@ -516,9 +516,11 @@ __global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __rest
     if (last2 < first2 || ma > last2) return;   // both waves leave
   }
   const int mb = ma + R - 1 < lim ? ma + R - 1 : lim;
-  // interior pair: rows ma - 6 .. mb + 6 in [3, nx - 1], columns c0 - 1 .. c0 + W in [1, ny + 1] with every lane's columns in [2, ny]
-  // (on a strip also inside the stored rows: the interior marches do not clamp their row addresses)
-  const bool interior = ma >= 9 && mb + 7 <= g.nx && ma - 6 >= g.row_lo && mb + 7 <= g.row_hi && c0 >= 2 && c0 + W - 1 <= g.ny;
+  // interior pair, stated as what the IN marches fold to constants: every row the pair loads, forms or tests (ma - 8 .. mb + 7: the
+  // x pipeline's "row strictly inside [ilo, ihi]" tests reach ma - 7 and mb + 6) lies inside the computable rows [ilo, ihi] -- on a
+  // full domain [1, nx], on a strip also inside the stored rows, whose addresses the interior marches do not clamp --, every row it
+  // counts Courant violations on is an owned row, columns c0 - 1 .. c0 + W lie in [1, ny + 1] with every lane's columns in [2, ny]
+  const bool interior = ma - 8 >= g.ilo && mb + 7 <= g.ihi && ma >= g.own_lo && mb <= g.own_hi && c0 >= 2 && c0 + W - 1 <= g.ny;
   if (role == 0) {
     if (interior) tm_transport_march<T, V, YFIRST, STORE_UV, BS, true, ABL>(g, c, ring, F, Fn, us, vs, p, Uo, Vo, courant, c0, lane, ma, mb, wt_);
     else tm_transport_march<T, V, YFIRST, STORE_UV, BS, false, ABL>(g, c, ring, F, Fn, us, vs, p, Uo, Vo, courant, c0, lane, ma, mb, wt_);

@@ -225,10 +225,14 @@ void tm5_head(vof2d_ctx* h) {
 template <typename T>
 void tm5_jacobi(vof2d_ctx* h, int par) {
   if (L<T>::jacobi_pair_ok(h)) {
+    // jacobi_iters / 10 launches of ten sweeps each, like batch_jacobi (an odd count leaves the host's view of the p / pt
+    // pair swapped: the exchange graphs are keyed by it)
     h->jpair_active = true;
-    L<T>::jacobi_pair(h, fP, fPT, par);
+    for (int j = 0; j < h->d.jacobi_iters / 10; ++j) {
+      L<T>::jacobi_pair(h, fP, fPT, par);
+      swap_P(h);
+    }
     h->jpair_active = false;
-    swap_P(h);
   } else {
     jacobi_n<T>(h, h->d.jacobi_iters, false, -1);
   }

@@ -179,6 +179,9 @@ struct vof2d_ctx {
   // batches alternate between the forms, the faster one stays (vof_step)
   int fuse_tm = -1;
   double gas_share = -1.0;   // what the rule saw (get_param "gas_share")
+  unsigned long long* h_gas = nullptr;   // pinned host word the count of exact-zero cells of F lands in (post_gas_count)
+  hipEvent_t ev_gas = nullptr;           // ... recorded behind the copy
+  bool gas_pending = false;              // a count of the current F is in flight or has landed, not yet read
   bool tm_broken = false;    // the k_tm batch graphs could not be captured: the other form stays
   bool alt_dirty = false;    // a verb or a field write left something in mx / my (the second u*, v* pair of the k_tm forms): cleared at the head of a strip call (tm5_head)
   bool ahead = false;        // u*, v*, rhs hold the predictor of step istep + 1 (the chained k_tm batches; settle_ahead)

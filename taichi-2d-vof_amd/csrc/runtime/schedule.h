@@ -450,7 +450,7 @@ void destroy_graphs(vof2d_ctx* h) {
     for (int k = 0; k < 2; ++k)
       for (int o = 0; o < 2; ++o)
         if (h->gbatch_tm[b][k][o]) { (void)hipGraphExecDestroy(h->gbatch_tm[b][k][o]); h->gbatch_tm[b][k][o] = nullptr; }
-  h->tune_n = 0; h->tune_age = 0; h->tm_decided = false; h->tm_broken = false; h->tune_ms[0] = h->tune_ms[1] = 0.f;   // (a changed knob changes what is being compared)
+  h->tune_n = 0; h->tune_age = 0; h->tm_decided = false; h->gas_pending = false; h->tm_broken = false; h->tune_ms[0] = h->tune_ms[1] = 0.f;   // (a changed knob changes what is being compared)
   for (int b = 0; b < vof2d_ctx::kStepBatches; ++b) h->halves_captured[b] = false;
   h->batching = true;   // (a parameter change may be what a capture tripped over: try again)
   for (int k = 0; k < 5; ++k)

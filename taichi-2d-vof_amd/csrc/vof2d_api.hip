@@ -65,8 +65,11 @@ int vof_create(const vof2d_desc* d, void* stream, vof2d_handle* out) {
   g.col0 = align - 1;                   // j = 1 lands on a 128-byte boundary
   // furthest column any lane touches: the overlapped tiles of k_fct_y / k_jacobi_tb start at most
   // H <= 12 columns left of j = 1 and their last tile may run a full tile past ny.
-  // (the fp32 pair kernels with four columns per lane: 256-column tiles)
+#ifdef VOF_PAIR_VEC4   // (experiment: the fp32 pair kernels with four columns per lane, 256-column tiles)
   long maxcol = (long)d->ny + (d->dtype == VOF_F32 ? 256 : W) + 16;
+#else
+  long maxcol = (long)d->ny + W + 16;
+#endif
   g.pitch = ((g.col0 + maxcol + 1 + align - 1) / align) * align;
   const size_t nrows = (size_t)(d->row_hi - d->row_lo + 1);
   h->field_elems = nrows * (size_t)g.pitch + (size_t)align;  // + one 128-byte tail pad
@@ -127,6 +130,8 @@ int vof_destroy(vof2d_handle h) {
   for (hipStream_t st : h->chain_streams) (void)hipStreamDestroy(st);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_gas) (void)hipEventDestroy(h->ev_gas);
+  if (h->h_gas) (void)hipHostFree(h->h_gas);
   comm_teardown(h);
   if (h->vis) (void)hipFree(h->vis);
 #ifdef VOF_SHORTCUT_STATS
@@ -146,13 +151,18 @@ int vof_destroy(vof2d_handle h) {
   return VOF_OK;
 }
 
+static bool post_gas_count(vof2d_ctx* h);   // (the batch-form rule of vof_step, below)
 int vof_set_init_F(vof2d_handle h, int32_t ic) {
   if (!h) return VOF_EINVAL;
   if (ic < 1 || ic > 3) return fail(h, VOF_EINVAL, "ic must be 1, 2 or 3 (2dvof.py:13)");
   settle_ghosts(h);
   DISPATCH_T(h, L<double>::init_F(h, ic), L<float>::init_F(h, ic));
   h->f_ghosts_dirty = true;
-  if (h->fuse_tm == -1) h->tm_decided = false;   // (the batch-form rule looks at the new F)
+  if (h->fuse_tm == -1) {   // (the batch-form rule looks at the new F: the count is taken now, asynchronously, and read by the first batched step)
+    h->tm_decided = false;
+    h->gas_pending = false;
+    if (tm_by_rule(h)) (void)post_gas_count(h);
+  }
   return ensure_ok(h);
 }
 int vof_set_BC(vof2d_handle h) {
@@ -307,20 +317,35 @@ static void build_step_batches(vof2d_ctx* h, int variant /* 0: chains or the pla
 // dam-break (5/6 gas) 0.49 against 0.56 ms/step for the chains, 4096^2 rising bubble (2 % gas) 0.81 against 0.61 -- so the
 // rule is the share of exact-zero cells of F when the handle first batches steps (and again after F was replaced from
 // outside): one small kernel and one 8-byte read-back, where the graphs are being captured anyway.
-static int decide_batch_form_by_rule(vof2d_ctx* h) {
+// The count is POSTED (kernel + 8-byte copy into pinned host memory + event, all asynchronous) where F is replaced as a
+// whole -- vof_set_init_F -- or, failing that, by the first step that needs it; vof_step only waits for the event, which
+// after set_init_F has long fired: no device sync inside a timed vof_step.  Anything that fails on the way (a caller's
+// stream under capture, no pinned memory) leaves the handle undecided and on the other form: never an error of vof_step.
+static bool post_gas_count(vof2d_ctx* h) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+  if (!h->h_gas && hipHostMalloc(reinterpret_cast<void**>(&h->h_gas), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->h_gas = nullptr; return false; }
+  if (!h->ev_gas && hipEventCreateWithFlags(&h->ev_gas, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->ev_gas = nullptr; return false; }
   unsigned long long* cnt = h->d_courant + 3;
-  HIPCHK(h, hipMemsetAsync(cnt, 0, sizeof(*cnt), h->stream));
+  bool ok = hipMemsetAsync(cnt, 0, sizeof(*cnt), h->stream) == hipSuccess;
   const unsigned blocks = (unsigned)(h->g.ihi - h->g.ilo + 1 < 2048 ? h->g.ihi - h->g.ilo + 1 : 2048);
   if (h->d.dtype == VOF_F64) hipLaunchKernelGGL(k_gas_cells<double>, dim3(blocks), dim3(256), 0, h->stream, h->g, (const double*)F_<double>(h, fF), cnt);
   else hipLaunchKernelGGL(k_gas_cells<float>, dim3(blocks), dim3(256), 0, h->stream, h->g, (const float*)F_<float>(h, fF), cnt);
-  unsigned long long n = 0;
-  HIPCHK(h, hipMemcpyAsync(&n, cnt, sizeof(n), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  ok = ok && hipMemcpyAsync(h->h_gas, cnt, sizeof(*cnt), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+  ok = ok && hipEventRecord(h->ev_gas, h->stream) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  h->gas_pending = ok;
+  return ok;
+}
+static void decide_batch_form_by_rule(vof2d_ctx* h) {
+  if (!h->gas_pending && !post_gas_count(h)) return;
+  h->gas_pending = false;
+  if (hipEventSynchronize(h->ev_gas) != hipSuccess) { (void)hipGetLastError(); return; }
+  const unsigned long long n = *h->h_gas;
   h->gas_share = (double)n / ((double)(h->g.ihi - h->g.ilo + 1) * (double)h->g.ny);
   h->tm_choice = (h->gas_share >= kTmGasShare || (long)(h->g.ihi - h->g.ilo + 1) * h->g.ny >= kTmAlwaysCells) ? 1 : 0;
   h->tm_decided = true;
   if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] batch form by rule: %.3f of the cells are gas -> %s\n", h->gas_share, h->tm_choice ? "k_tm" : "chains / plain");
-  return VOF_OK;
 }
 
 int vof_step(vof2d_handle h, int64_t nsteps) {
@@ -353,11 +378,8 @@ int vof_step(vof2d_handle h, int64_t nsteps) {
       int variant = (h->fuse_tm > 0 && tm_eligible(h)) ? 1 : 0;
       bool timed = false;
       if (tm_by_rule(h)) {
-        if (!h->tm_decided) {
-          const int rc = decide_batch_form_by_rule(h);
-          if (rc) { h->istep -= 1; return rc; }
-        }
-        variant = h->tm_choice;
+        if (!h->tm_decided) decide_batch_form_by_rule(h);
+        variant = h->tm_decided ? h->tm_choice : 0;   // (undecided -- the count could not be taken: the other form, and another try next call)
       } else if (tm_auto(h)) {   // fuse_tm = -2 (exploration): both forms timed on the handle's own data
         if (h->tune_n == 4) {
           bool done = hipEventSynchronize(h->tune_ev[7]) == hipSuccess;
@@ -593,7 +615,7 @@ int vof_set_rows(vof2d_handle h, const char* name, int32_t g0, int32_t g1, const
   if (id < 0) return fail(h, VOF_EINVAL, "unknown field name");
   int rc = copy_rows_host(h, id, g0, g1, const_cast<void*>(src), nbytes, false);
   if (rc == VOF_OK && id == fF) rc = copy_rows_host(h, fF2, g0, g1, const_cast<void*>(src), nbytes, false);
-  if (id == fF || id == fF2) { h->f_ghosts_dirty = true; if (h->fuse_tm == -1) h->tm_decided = false; }
+  if (id == fF || id == fF2) { h->f_ghosts_dirty = true; if (h->fuse_tm == -1) { h->tm_decided = false; h->gas_pending = false; } }
   if (id == fMX || id == fMY) h->alt_dirty = true;
   if (id == fU || id == fV) h->uv_ghosts_dirty = true;
   return rc;
@@ -642,7 +664,7 @@ int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t 
                                reinterpret_cast<char*>(src->fld[fF]) + off_s, bytes, hipMemcpyDeviceToDevice,
                                dst->stream));
   if (dst->g.wall_lo && dst->g.wall_hi) {  // a full domain: the rows' neighbours' ghost cells may no longer mirror them
-    if (id == fF) { dst->f_ghosts_dirty = true; if (dst->fuse_tm == -1) dst->tm_decided = false; }
+    if (id == fF) { dst->f_ghosts_dirty = true; if (dst->fuse_tm == -1) { dst->tm_decided = false; dst->gas_pending = false; } }
     if (id == fMX || id == fMY) dst->alt_dirty = true;
     if (id == fU || id == fV) dst->uv_ghosts_dirty = true;
   }

@@ -7,7 +7,7 @@ which exports the same signatures with prefix ``ovof_``.
 """
 import ctypes as C
 
-VOF_ABI_VERSION = 1
+VOF_ABI_VERSION = 2
 VOF_F64, VOF_F32 = 0, 1
 VOF_OK, VOF_EINVAL, VOF_EHIP, VOF_ENOMEM, VOF_ESTATE = 0, -1, -2, -3, -4
 VOF_FLAG_NO_GRAPH = 1

@@ -30,6 +30,21 @@ from .engine import Engine, make_desc
 
 EXCHANGED = ("F", "u", "v", "p")
 EXCHANGED_MODE5 = ("u_star", "v_star")      # next to F and p: the exchange state with the step boundary behind the predictor
+EXCHANGED_PIECES = ("rhs",)                 # ... and what the library's pair kernels ship with them (vof_step_tm_piece)
+
+
+class _StagedWork:
+    """The works of one host-staged exchange (see StripSolver.stage_host): wait for the gloo transfers, then copy the
+    received rows from their host buffers into field memory."""
+
+    def __init__(self, works, landings):
+        self.works, self.landings = works, landings
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for dst, src in self.landings:
+            dst.copy_(src)
 
 
 def partition(nx, world):
@@ -87,7 +102,7 @@ class StripSolver:
     With an EnvComm and the native exchange the process never imports torch."""
 
     def __init__(self, nx, ny, dtype="f64", ic=1, coord_cast="f32", jacobi_iters=10, rank=0, world=1,
-                 device=None, api=None, dist=None, exchange="auto", comm=None, parts=None, **consts):
+                 device=None, api=None, dist=None, exchange="auto", comm=None, parts=None, stage_host=None, **consts):
         if exchange not in ("auto", "native", "torch"):
             raise ValueError("exchange must be 'auto', 'native' or 'torch'")
         if api is None:
@@ -126,7 +141,14 @@ class StripSolver:
                 self.stream = torch.cuda.Stream(device=dev)
                 stream_ptr = self.stream.cuda_stream
                 self.device = dev
-        self.comm = comm if comm is not None else (TorchComm(self.dist, rank, world, self.device) if world > 1 else None)
+        # stage_host: the torch carrier's P2P ops run on host buffers, the rows copied out of / into field memory around
+        # them -- what a backend that cannot move device memory needs (gloo: the N > 1 rehearsal of bench.py --same-device,
+        # two processes on ONE GPU, where RCCL refuses to form a communicator).  Default: on the GPU under gloo.
+        if stage_host is None:
+            stage_host = bool(self.on_gpu and self.dist is not None and world > 1 and self.dist.get_backend() == "gloo")
+        self.stage_host = bool(stage_host) and world > 1 and not torch_free      # (asked for explicitly it also runs over the CPU engine: the gloo tests)
+        self._fresh = True          # no step since set_init_F: the first one runs with the reference's intermediate set_BC calls
+        self.comm = comm if comm is not None else (TorchComm(self.dist, rank, world, None if self.stage_host else self.device) if world > 1 else None)
         desc = make_desc(api, nx, ny, dtype, coord_cast, rows=self.rows, own=self.own,
                          jacobi_iters=jacobi_iters, device=(device if device is not None else 0) if self.on_gpu else -1,
                          **consts)
@@ -178,7 +200,7 @@ class StripSolver:
         torch = self.torch
         tdt = torch.float64 if self.eng.np_dtype == np.float64 else torch.float32
         typestr = "<f8" if self.eng.np_dtype == np.float64 else "<f4"
-        for f in EXCHANGED + EXCHANGED_MODE5:
+        for f in EXCHANGED + EXCHANGED_MODE5 + (EXCHANGED_PIECES if self.on_gpu else ()):
             base, pitch, col0, nrows = self.eng.field_view(f)
             if self.on_gpu:
                 t = torch.as_tensor(_DevArray(base, (nrows, pitch), typestr), device=self.device)
@@ -222,10 +244,34 @@ class StripSolver:
         """Post the halo send/recvs of `fields` with both neighbours as one batched P2P group;
         returns the outstanding works.  RCCL orders the transfers after everything already
         enqueued on the solver's stream and runs them on its own stream."""
+        if self.stage_host:
+            return self._exchange_staged(fields)
         ops = []
         for f in fields:
             ops += self._p2p_ops(f)
         return self.dist.batch_isend_irecv(ops) if ops else []
+
+    def _exchange_staged(self, fields):
+        """The same messages through host memory: the W owned rows next to each interior edge are copied to the host
+        (which waits for the kernels that produced them), sent / received by the host backend, and the received rows
+        copied into the halo rows when the work is waited for."""
+        dist, W = self.dist, self.halo
+        lo, hi = self.own
+        ops, landings = [], []
+        for f in fields:
+            if self.rank > 0:
+                ops.append(dist.P2POp(dist.isend, self._rows_view(f, lo, lo + W - 1).cpu(), self.rank - 1))
+                dst = self._rows_view(f, lo - W, lo - 1)
+                buf = self.torch.empty(dst.shape, dtype=dst.dtype, device="cpu")
+                ops.append(dist.P2POp(dist.irecv, buf, self.rank - 1))
+                landings.append((dst, buf))
+            if self.rank < self.world - 1:
+                ops.append(dist.P2POp(dist.isend, self._rows_view(f, hi - W + 1, hi).cpu(), self.rank + 1))
+                dst = self._rows_view(f, hi + 1, hi + W)
+                buf = self.torch.empty(dst.shape, dtype=dst.dtype, device="cpu")
+                ops.append(dist.P2POp(dist.irecv, buf, self.rank + 1))
+                landings.append((dst, buf))
+        return [_StagedWork(dist.batch_isend_irecv(ops), landings)] if ops else []
 
     def exchange(self, fields=EXCHANGED):
         """Refresh the halo rows of `fields` from both neighbours and wait for them."""
@@ -235,8 +281,9 @@ class StripSolver:
             bit = {"F": _abi.VOF_XCHG_F, "u": _abi.VOF_XCHG_U, "v": _abi.VOF_XCHG_V, "p": _abi.VOF_XCHG_P}
             self.eng.comm_exchange(sum(bit[f] for f in fields))
             return
-        for w in self._exchange_async(fields):
-            w.wait()
+        with self._ctx():          # (ordered behind the kernels on the solver's stream)
+            for w in self._exchange_async(fields):
+                w.wait()
 
     def _ctx(self):
         import contextlib
@@ -255,8 +302,11 @@ class StripSolver:
             # the whole loop in the library; True = the default schedule (mode 4: fused transport, edge bands
             # first, one send/recv group per step), an int = that mode of vof_step_exchange
             self.eng.step_exchange(nsteps, 4 if overlap is True else int(overlap))
+            self._fresh = False
             return
         if self.world > 1 and overlap == 5 and overlap is not True:
+            if self.on_gpu:
+                return self._step_pieces(nsteps)
             return self._step_boundary_behind_the_predictor(nsteps)
         with self._ctx():
             for _ in range(nsteps):
@@ -266,14 +316,43 @@ class StripSolver:
                     self.eng.step(1)
                     self.exchange()
                 else:
-                    self.eng.step_phase(0)
-                    works = self._exchange_async(("p",))
-                    self.eng.step_phase(1)
-                    works += self._exchange_async(("u", "v"))
-                    self.eng.step_phase(2)
-                    works += self._exchange_async(("F",))
-                    for w in works:
-                        w.wait()
+                    self._phased_step()
+            self._fresh = False
+
+    def _phased_step(self):
+        self.eng.step_phase(0)
+        works = self._exchange_async(("p",))
+        self.eng.step_phase(1)
+        works += self._exchange_async(("u", "v"))
+        self.eng.step_phase(2)
+        works += self._exchange_async(("F",))
+        for w in works:
+            w.wait()
+
+    def _step_pieces(self, nsteps):
+        """Overlap mode 5 on the GPU with the halos carried by torch.distributed instead of the library's own RCCL
+        communicator: the kernels of vof_step_exchange(.., 5) piece by piece (vof_step_tm_piece: k_momentum on the owned
+        rows; k_jacobi_pair + k_tm per middle step; the last step as mode 4's) with one exchange behind each -- what the
+        second carrier of bench.py --gpus N runs, and its one-GPU rehearsal (--same-device, gloo, host-staged)."""
+        e = self.eng
+
+        def trade(fields):
+            for w in self._exchange_async(fields):
+                w.wait()
+        with self._ctx():
+            if nsteps > 0 and self._fresh:       # (the first step after set_init_F: the phases carry the reference's set_BC calls)
+                self._phased_step()
+                self._fresh = False
+                nsteps -= 1
+            if nsteps <= 0:
+                return
+            e.step_tm_piece(0)
+            trade(EXCHANGED_MODE5 + EXCHANGED_PIECES)
+            for _ in range(nsteps - 1):
+                e.step_tm_piece(1)
+                trade(("F", "p") + EXCHANGED_MODE5 + EXCHANGED_PIECES)
+            e.step_tm_piece(2)
+            trade(EXCHANGED)
 
     def _step_boundary_behind_the_predictor(self, nsteps):
         """The torch carrier's form of overlap mode 5 (verb by verb: what the gloo tests drive; on the GPU the library runs

@@ -3,7 +3,7 @@ never imports torch, so that the library binds the system RCCL (ROCm 7.2: 2.27.7
 groups can be captured into the step graph) and not the 2.26.6 PyTorch bundles, and the captured
 exchange -- what `bench.py --gpus N` runs by default -- is what is asserted, strictly.
 
-    python tests/_loopback_worker.py modes | mode4 LO HI
+    python tests/_loopback_worker.py modes | mode4 LO HI | mode5 LO HI [f64|f32 [JACOBI_ITERS]]
 """
 import contextlib
 import os
@@ -153,18 +153,20 @@ def exchange_mode4_equals_phases_plus_copies(hip_api, own):
     e.comm_destroy(); e.close(); ref.close()
 
 
-def exchange_mode5_equals_pieces_plus_copies(hip_api, own):
+def exchange_mode5_equals_pieces_plus_copies(hip_api, own, dtype="f64", iters=10):
     """vof_step_exchange overlap 5 (the strips run k_jacobi_pair and k_tm; F, u*, v*, rhs, p exchanged once per step, the
     edge bands of k_tm on the communication stream in front of the send / recv group, the other rows beside them) with the
     neighbours looped back: the middle steps replayed from captured graphs, two per launch, must equal the same kernels
     piece by piece (vof_step_tm_piece) with hand-made halo copies, on every stored row, ghost cells included."""
     from vof2d import _abi
     from vof2d.engine import Engine, make_desc, comm_unique_id
-    nx, ny, W = 200, 96, _abi.halo_rows(10)
+    # (iters = 20, 30: every middle step runs iters / 10 launches of k_jacobi_pair -- ADVICE r05; fp32: the same kernels, mode 5 in
+    # both precisions since round 6)
+    nx, ny, W = 200, 96, _abi.halo_rows(iters)
     rows = (max(0, own[0] - W), min(nx + 1, own[1] + W))
     wall_lo, wall_hi = own[0] == 1, own[1] == nx
-    e = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
-    ref = Engine(hip_api, make_desc(hip_api, nx, ny, "f64", "f32", rows=rows, own=own, device=0))
+    e = Engine(hip_api, make_desc(hip_api, nx, ny, dtype, "f32", rows=rows, own=own, device=0, jacobi_iters=iters))
+    ref = Engine(hip_api, make_desc(hip_api, nx, ny, dtype, "f32", rows=rows, own=own, device=0, jacobi_iters=iters))
     for x in (e, ref):
         x.set_init_F(3)
     e.comm_init(comm_unique_id(hip_api), 0, 1, loopback=True)
@@ -210,7 +212,7 @@ if __name__ == "__main__":
     if sys.argv[1] == "modes":
         native_rccl_exchange_loopback(api)
     elif sys.argv[1] == "mode5":
-        exchange_mode5_equals_pieces_plus_copies(api, (int(sys.argv[2]), int(sys.argv[3])))
+        exchange_mode5_equals_pieces_plus_copies(api, (int(sys.argv[2]), int(sys.argv[3])), *(sys.argv[4:5] or ["f64"]), *(int(x) for x in sys.argv[5:6]))
     else:
         exchange_mode4_equals_phases_plus_copies(api, (int(sys.argv[2]), int(sys.argv[3])))
     assert "torch" not in sys.modules, "the worker must stay torch-free"

@@ -18,14 +18,15 @@ def oracle_api():
     return _abi.bind(lib, "ovof_", optional=_abi.GPU_ONLY)
 
 
-def run(rank, world, port, nx, ny, ic, dtype, steps, outdir, overlap=True, parts=None):
+def run(rank, world, port, nx, ny, ic, dtype, steps, outdir, overlap=True, parts=None, stage_host=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       OMP_NUM_THREADS="1")
     import torch.distributed as dist
     from vof2d.strips import StripSolver
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        s = StripSolver(nx, ny, dtype, ic=ic, rank=rank, world=world, api=oracle_api(), dist=dist, parts=parts)
+        s = StripSolver(nx, ny, dtype, ic=ic, rank=rank, world=world, api=oracle_api(), dist=dist, parts=parts, stage_host=stage_host)
+        assert s.stage_host == bool(stage_host)
         s.step(steps, overlap=overlap)
         fields = {f: s.gather(f) for f in ("F", "u", "v", "p")}
         it, res = s.solve_p_residual(1e-9, 40, 10)

@@ -109,6 +109,12 @@ def test_bench_starts_its_own_workers_when_no_launcher_did():
     assert [x["local_rank"] for x in d["ranks"]] == [0, 1, 2, 3] and all(x["world"] == 4 for x in d["ranks"])
     assert len({x["token"] for x in d["ranks"]}) == 1 and len({x["master"] for x in d["ranks"]}) == 1
     assert d["ranks"][0]["master"].startswith("127.0.0.1:")
+    # --same-device (the one-GPU rehearsal of the N > 1 path): every rank is handed device 0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--same-device"], capture_output=True,
+                       text=True, timeout=120, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert [x["local_rank"] for x in d["ranks"]] == [0, 0] and all(x["same_device"] for x in d["ranks"])
 
 
 def test_self_started_run_ends_when_a_worker_dies():
@@ -172,6 +178,39 @@ def test_bench_strip_path_with_one_rank_torch_carrier():
     d, err = _run_bench(["--force-dist", "--exchange", "torch", "--nx", "1024", "--steps", "6", "--warmup", "2",
                          "--jacobi-sweeps-timed", "20"])
     assert d["n_gpus"] == 1 and d["config"]["rows_per_rank"] == [1024] and d["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,nx,overlap", [("f64", 1024, 5), ("f32", 768, 4)])
+def test_bench_two_ranks_rehearsed_on_one_device(dtype, nx, overlap):
+    """`bench.py --gpus 2 --same-device`: the N > 1 path end to end on the one GPU of the test box -- the GPU-free launcher starts
+    two fresh workers, each rank's supervisor its child; the children meet in the rendezvous directory (EnvComm), RCCL refuses a
+    communicator of two ranks on one device, the halos travel by the second carrier (gloo, rows staged through host memory);
+    cost probe and re-cut, warm-up, timed region, the same-grid single-GPU leg, the N > 1 line.  The fields the two strips end
+    with (SHA-256 in the line) are the single domain's after the same number of steps."""
+    import hashlib
+    from vof2d._lib import hip_api
+    from vof2d.engine import Engine, make_desc
+    steps, warmup = 7, 4
+    d, err = _run_bench(["--gpus", "2", "--same-device", "--digest", "--nx", str(nx), "--dtype", dtype, "--steps", str(steps), "--warmup", str(warmup),
+                         "--jacobi-sweeps-timed", "20", "--overlap", str(overlap), "--attempt-timeout", "240"], timeout=1500)
+    assert d["n_gpus"] == 2 and d["steps"] == steps and d["value"] > 0 and d["scaling"] == "strong"
+    c = d["config"]
+    assert c["same_device_rehearsal"] is True and c["multi_gpu_hardware_verified"] is False
+    assert len(c["rows_per_rank"]) == 2 and sum(c["rows_per_rank"]) == nx and min(c["rows_per_rank"]) >= 18
+    assert c["exchange"].startswith("torch/gloo") and c["overlap"] == overlap
+    assert "native RCCL exchange unavailable" in err                       # (the first carrier was tried: rendezvous + vof_comm_init)
+    ref1 = d["strong_scaling_reference_n1"]
+    assert ref1 and ref1["value"] > 0 and d["speedup_same_grid"] > 0       # the same-grid single-GPU leg ran beside it
+    api = hip_api()
+    e = Engine(api, make_desc(api, nx, nx, dtype, "f32", device=0, dt=c["dt"]))
+    e.set_init_F(1)
+    e.step(steps + warmup)
+    got = d["fields_sha256"]
+    assert got["istep"] == steps + warmup and got["shape"] == [nx + 2, nx + 2]
+    for f in ("F", "u", "v", "p"):
+        assert got[f] == hashlib.sha256(e.get(f).tobytes()).hexdigest(), "field %s of the two strips differs from the single domain's" % f
+    e.close()
 
 
 @pytest.mark.gpu

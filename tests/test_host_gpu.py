@@ -125,6 +125,13 @@ def test_exchange_mode5_equals_pieces_plus_copies(own):
     _loopback_worker("mode5", own[0], own[1])
 
 
+@pytest.mark.parametrize("own,dtype,iters", [((61, 140), "f32", 10), ((1, 100), "f32", 10), ((71, 150), "f64", 20), ((101, 200), "f32", 20)])
+def test_exchange_mode5_in_fp32_and_with_more_sweeps(own, dtype, iters):
+    """Overlap mode 5 in fp32 (what bench.py --gpus N --dtype f32 runs since round 6) and with 20 sweeps per step: every
+    middle step runs jacobi_iters / 10 launches of k_jacobi_pair (round 5 ran one whatever the count: ADVICE r05)."""
+    _loopback_worker("mode5", own[0], own[1], dtype, iters)
+
+
 def test_command_line_residual_terminated_solve(tmp_path):
     """2dvof.py --jacobi-tol / --jacobi-crit (extension): the main loop :513-528 with vof_solve_p in place of
     the ten fixed sweeps runs headless and reports like the reference."""

@@ -887,6 +887,32 @@ def test_k_tm_batches_chain_across_calls(hip_api, oracle_api, dtype, ic, nx, ny)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,iters", [("f64", 20), ("f32", 30), ("f64", 15)])
+def test_strip_pieces_run_every_sweep(hip_api, oracle_api, dtype, iters):
+    """A middle step of overlap mode 5 (vof_step_tm_piece(1): tm5_jacobi + k_tm) runs jacobi_iters sweeps -- jacobi_iters / 10
+    launches of k_jacobi_pair where the pair kernel applies (20, 30), five-sweep launches where it does not (15) -- not ten
+    whatever the count (jacobi_pair_ok only asks for a multiple of ten)."""
+    n = 320
+    a = engine(hip_api, n, n, dtype, "f32", ic=3, jacobi_iters=iters)
+    b = engine(hip_api, n, n, dtype, "f32", ic=3, jacobi_iters=iters)
+    b.set_param("overlap_halves", 0)
+    b.set_param("fuse_tm", 0)
+    o = engine(oracle_api, n, n, dtype, "f32", ic=3, jacobi_iters=iters)
+    for e in (a, b, o):
+        e.step(1)
+    for call in (4, 7, 2):
+        a.step_tm_piece(0)
+        for _ in range(call - 1):
+            a.step_tm_piece(1)
+        a.step_tm_piece(2)
+        for e in (b, o):
+            e.step(call)
+        assert a.istep == o.istep
+        assert_fields_same(a, b, STATE + ("u_star", "v_star", "rhs"), ctx="strip pieces, %d sweeps per step, %s, step %d" % (iters, dtype, a.istep))
+        assert_fields_same(a, o, ctx="strip pieces / oracle, %d sweeps per step, %s, step %d" % (iters, dtype, a.istep))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,ic,nx,ny", [("f64", 1, 2048, 2048), ("f64", 2, 1536, 3000), ("f32", 3, 2048, 2048)])
 def test_fused_transport_momentum_mid_size_twice(hip_api, dtype, ic, nx, ny):
     """k_tm on grids of a few million cells, twice, against the plain sequence.  The store-data hazard of round 4 (a

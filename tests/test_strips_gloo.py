@@ -59,6 +59,25 @@ def test_strips_with_an_uneven_partition_equal_single_domain(oracle_api, tmp_pat
         assert same(z[f], ref.get(f)), diff_report(z[f], ref.get(f), f)
 
 
+def test_strips_with_host_staged_halos_equal_single_domain(oracle_api, tmp_path):
+    """StripSolver(stage_host=True): the halo rows go through host buffers around the P2P ops (what the one-GPU rehearsal of the
+    N > 1 path, bench.py --gpus 2 --same-device, runs over gloo with the HIP engine) -- three ranks, uneven strips, phased
+    exchanges, then the residual solve's p exchanges."""
+    import torch.multiprocessing as mp
+    import _strip_worker
+    nx, ny, steps, world = 90, 28, 9, 3
+    parts = [(1, 30), (31, 52), (53, 90)]
+    mp.spawn(_strip_worker.run, args=(world, _free_port(), nx, ny, 3, "f64", steps, str(tmp_path), True, parts, True),
+             nprocs=world, join=True)
+    z = np.load(tmp_path / "strips.npz")
+    ref = engine(oracle_api, nx, ny, "f64", "f32", ic=3)
+    ref.step(steps)
+    for f in ("F", "u", "v", "p"):
+        assert same(z[f], ref.get(f)), diff_report(z[f], ref.get(f), f)
+    it, res = ref.solve_p_residual(1e-9, 40, 10)
+    assert int(z["it"]) == it and float(z["res"]) == res and same(z["p_after"][1:-1], ref.get("p")[1:-1])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
