@@ -312,6 +312,25 @@ __device__ __forceinline__ T div_scaled(T a, T b, T y, T scale) {  // RN((a * sc
   return dfma<T>(dfma<T>(-b, Q0, A), y, Q0);
 }
 
+// The tiny tier, |a| < lo, WITHOUT a branch (round 6): the scaled quotient, its rounding onto the subnormal grid and the repair of
+// the double rounding are a straight run of a dozen instructions with three selects at the end -- as nested branches (rounds 1-5)
+// the same arithmetic carried as many scalar instructions again (exec masks saved, tested, restored at three levels), in kernels
+// whose waves issue one instruction at a time.  |Q| >= qmin needs no test: there Q * dn is exact, diff is 0 and nothing is repaired.
+// An exact zero returns a * y (the signed zero of the quotient).
+template <typename T>
+__device__ __forceinline__ T div_tiny(T a, T b, T y) {
+  using L = DivLimits<T>;
+  const T A = a * L::up;
+  const T Q = div_scaled<T>(a, b, y, L::up);    // RN((a * up) / b): the fast form is exact here
+  T res = Q * L::dn;                            // exact if |Q| >= qmin, else RN onto the subnormal grid
+  const T diff = dfma<T>(-res, L::up, Q);       // Q - res * up, exact; +-half_step iff Q is a grid midpoint
+  const T R = dfma<T>(-b, Q, A);                // exact remainder: true quotient - Q = R / b
+  const bool fix = dabs<T>(diff) == L::half_step && R != (T)0 && ((R > (T)0) == (b > (T)0)) == (diff > (T)0);
+  const T adj = res + (diff > (T)0 ? L::denorm_min : -L::denorm_min);
+  res = fix ? adj : res;
+  return a != (T)0 ? res : a * y;
+}
+
 template <typename T, bool SMALL_B = false>
 __device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
   using L = DivLimits<T>;
@@ -320,17 +339,8 @@ __device__ __forceinline__ T div_by_const(T a, T b, T y /* = 1 / b */) {
   T res = dfma<T>(r, y, q);
   const T aa = dabs<T>(a);
   if (aa < L::lo) {
-    res = q;                                    // a == 0: signed zero of the quotient
-    if (a != (T)0) {
-      const T Q = div_scaled<T>(a, b, y, L::up);
-      res = Q * L::dn;                          // exact if |Q| >= qmin, else RN onto the subnormal grid
-      if (!(dabs<T>(Q) >= L::qmin)) {
-        const T diff = Q - res * L::up;         // exact; +-half_step iff Q is a grid midpoint
-        const T R = dfma<T>(-b, Q, a * L::up);  // exact remainder: true quotient - Q = R / b
-        if (dabs<T>(diff) == L::half_step && R != (T)0 && ((R > (T)0) == (b > (T)0)) == (diff > (T)0))
-          res += diff > (T)0 ? L::denorm_min : -L::denorm_min;
-      }
-    }
+    res = q;                                    // a == 0 (the common case of the transport's flux differences): the signed zero of the quotient
+    if (a != (T)0) res = div_tiny<T>(a, b, y);
   } else if (SMALL_B && aa > L::hi) {
     res = q;                                    // infinite a: the infinity a * y
     if (aa < L::inf) res = div_scaled<T>(a, b, y, L::dn) * L::up;
@@ -382,7 +392,13 @@ __device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], con
     }
     if (odd) {   // (lanes holding a tiny non-zero or a huge / non-finite numerator only)
 #pragma unroll
-      for (int q = 0; q < V; ++q) res[q] = div_by_const<T, SMALL_B>(a[q], b[q], y[q]);
+      for (int q = 0; q < V; ++q) {
+        if constexpr (SMALL_B) res[q] = div_by_const<T, true>(a[q], b[q], y[q]);
+        else {
+          res[q] = dabs<T>(a[q]) < DivLimits<T>::lo ? div_tiny<T>(a[q], b[q], y[q]) : res[q];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       cold();
     }
   } else {
@@ -403,7 +419,13 @@ __device__ __forceinline__ void div_by_const_v(T (&res)[V], const T (&a)[V], con
       }
       if (nonzero) {
 #pragma unroll
-        for (int q = 0; q < V; ++q) res[q] = div_by_const<T, SMALL_B>(a[q], b[q], y[q]);
+        for (int q = 0; q < V; ++q) {
+          if constexpr (SMALL_B) res[q] = div_by_const<T, true>(a[q], b[q], y[q]);
+          else {
+            res[q] = dabs<T>(a[q]) < DivLimits<T>::lo ? div_tiny<T>(a[q], b[q], y[q]) : res[q];
+            __builtin_amdgcn_sched_barrier(0);   // one cell after the other: interleaved, the cells' temporaries cost k_jacobi_pair its fourth wave per SIMD (127 -> 129 VGPRs)
+          }
+        }
         cold();
       }
     }

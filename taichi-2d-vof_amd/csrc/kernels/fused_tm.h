@@ -320,6 +320,12 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
 #pragma unroll
   for (int q = 0; q < V; ++q) F3c[q] = mx2[q] = mx3[q] = my2[q] = k3[q] = us3[q] = vs3[q] = rho3[q] = (T)0;
   bool flat2 = true, flat1 = true, flat0;
+  // Rows of uniform F (gas, or liquid away from the interface: nine rows in ten of a dam-break) -- wave-level history of
+  // `flat` (the three newest rows uniform and equal), bit k = the iteration k before this one.  What it lets a row skip is
+  // exact: the skipped arithmetic would produce the same zeros / the same rho, nu from the same F (round 6).
+  unsigned flat_hist = 0u;
+  // (the force terms of a flat window are +-0; they enter u*, v* as (... + gx) + fx: the sum in front is never -0 unless gx is)
+  const bool zero_force_ok = !(c.gx == (T)0 && __builtin_signbit(c.gx)) && !(c.gy == (T)0 && __builtin_signbit(c.gy));
   Row<T, V> un, vn;   // u / v row r-1 of the coming iteration
   zero_row(un); zero_row(vn);
   for (int t = t_lo; t <= t_hi; ++t) {
@@ -349,7 +355,13 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
       T mx1[V], my1[V];
       flat0 = row_flat<T, V>(F0);
       const bool flat = flat2 && flat1 && flat0 && F2.c[0] == F1.c[0] && F1.c[0] == F0.c[0];
-      if (__all(flat)) {
+      const bool wflat = __all(flat);
+#ifdef VOF_NO_FLAT_SHORTCUTS      // (A/B builds: make variant NAME=noflat EXTRA=-DVOF_NO_FLAT_SHORTCUTS)
+      flat_hist = 0u;
+#else
+      flat_hist = __builtin_amdgcn_readfirstlane((flat_hist << 1) | (wflat ? 1u : 0u));
+#endif
+      if (wflat) {
 #pragma unroll
         for (int q = 0; q < V; ++q) mx1[q] = my1[q] = (T)0;
       } else {
@@ -364,31 +376,52 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
       }
       // ---- K: kappa of row r-2 (:307-309)
       const bool okK = IN || ((r - 2) >= ilo && (r - 2) <= ihi);
-      const T myl = lane_up(my2[V - 1]), myr = lane_dn(my2[0]);
       T k2[V];
+      if ((flat_hist & 7u) == 7u) {
+        // flat for three iterations: mx1, mx3 and every my2 of the wave are the +0 the flat branch above assigned
+        const T kk = -(c.kap_x * ((T)0 - (T)0) + c.kap_y * ((T)0 - (T)0));
 #pragma unroll
-      for (int q = 0; q < V; ++q) {
-        const T yr = q == V - 1 ? myr : my2[q + 1], yl = q == 0 ? myl : my2[q - 1];
-        const T kk = -(c.kap_x * (mx1[q] - mx3[q]) + c.kap_y * (yr - yl));
-        k2[q] = (okK && dom[q]) ? kk : (T)0;
+        for (int q = 0; q < V; ++q) k2[q] = (okK && dom[q]) ? kk : (T)0;
+      } else {
+        const T myl = lane_up(my2[V - 1]), myr = lane_dn(my2[0]);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          const T yr = q == V - 1 ? myr : my2[q + 1], yl = q == 0 ? myl : my2[q - 1];
+          const T kk = -(c.kap_x * (mx1[q] - mx3[q]) + c.kap_y * (yr - yl));
+          k2[q] = (okK && dom[q]) ? kk : (T)0;
+        }
       }
       // ---- P: u*, v* of row i = r-2 (:206-233)
       const int i = r - 2;
       const bool okP = IN || (i >= ilo && i <= ihi);
-      const T kl = lane_up(k2[V - 1]);
-      T us2[V], vs2[V], rho2[V];
+      T us2[V], vs2[V], rho2[V], nu2[V];
+      T rho2l;
+      if ((flat_hist & 3u) != 0u) {   // row r-2 is uniform (it belongs to a flat window): one rho, one nu
+        const T rf = rho_of(c, F2.c[0]), nf = nu_of(c, F2.c[0]);
 #pragma unroll
-      for (int q = 0; q < V; ++q) rho2[q] = rho_of(c, F2.c[q]);
-      const T rho2l = rho_of(c, F2.l);
+        for (int q = 0; q < V; ++q) { rho2[q] = rf; nu2[q] = nf; }
+        rho2l = rf;
+      } else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) { rho2[q] = rho_of(c, F2.c[q]); nu2[q] = nu_of(c, F2.c[q]); }
+        rho2l = rho_of(c, F2.l);
+      }
       T fxf[V], fyf[V];
       bool any_force = false;
+      if ((flat_hist & 2u) != 0u && zero_force_ok) {
+        // rows r-3, r-2 (and r-1) uniform and equal: F00 - Fm0 and F00 - F0m are +0, the force numerators +-0 whatever kappa is
 #pragma unroll
-      for (int q = 0; q < V; ++q) {
-        const T F00 = F2.c[q], Fm0 = F3c[q], F0m = left_of(F2, q);
-        const T k00 = k2[q], km0 = k3[q], k0m = q == 0 ? kl : k2[q - 1];
-        fxf[q] = -c.sigma * (F00 - Fm0) * ((k00 + km0) / (T)2.0);
-        fyf[q] = -c.sigma * (F00 - F0m) * ((k00 + k0m) / (T)2.0);
-        any_force = any_force || fxf[q] != (T)0 || fyf[q] != (T)0;
+        for (int q = 0; q < V; ++q) fxf[q] = fyf[q] = (T)0;
+      } else {
+        const T kl = lane_up(k2[V - 1]);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          const T F00 = F2.c[q], Fm0 = F3c[q], F0m = left_of(F2, q);
+          const T k00 = k2[q], km0 = k3[q], k0m = q == 0 ? kl : k2[q - 1];
+          fxf[q] = -c.sigma * (F00 - Fm0) * ((k00 + km0) / (T)2.0);
+          fyf[q] = -c.sigma * (F00 - F0m) * ((k00 + k0m) / (T)2.0);
+          any_force = any_force || fxf[q] != (T)0 || fyf[q] != (T)0;
+        }
       }
       if (any_force) {
 #pragma unroll
@@ -407,7 +440,7 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
         const T upm = left_of(u1, q);
         const T v00 = v2.c[q], vm0 = v3.c[q], vp0 = v1.c[q], v0m = left_of(v2, q), v0p = right_of(v2, q);
         const T vmp = right_of(v3, q);
-        const T nu00 = nu_of(c, F2.c[q]);
+        const T nu00 = nu2[q];
         T ou, ov;
         {
           T v_here = (T)0.25 * (vm0 + vmp + v00 + v0p);
@@ -477,8 +510,9 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
   }
 }
 
+// (three waves per SIMD: <= 168 VGPRs in every instantiation -- the forms with exec-masked global stores would take 171)
 template <typename T, int V, bool YFIRST, bool STORE_UV, bool BS, int ABL = 0>
-__global__ __launch_bounds__(128) void k_tm(Geom g, Consts<T> c, const T* __restrict__ F, T* __restrict__ Fn, int ntf,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void k_tm(Geom g, Consts<T> c, const T* __restrict__ F, T* __restrict__ Fn, int ntf,
                                             const T* __restrict__ us, const T* __restrict__ vs, const T* __restrict__ p,
                                             T* __restrict__ Uo, T* __restrict__ Vo, T* __restrict__ us_out,
                                             T* __restrict__ vs_out, T* __restrict__ rhs,

@@ -262,7 +262,7 @@ __device__ __forceinline__ void jacobi_pair_march(const Geom& g, const Consts<T>
 }
 
 template <typename T, int V, int TS, bool BS, int ABL = 0>
-__global__ __launch_bounds__(128) void k_jacobi_pair(Geom g, Consts<T> c, const T* __restrict__ p,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void k_jacobi_pair(Geom g, Consts<T> c, const T* __restrict__ p,
                                                      const T* __restrict__ rhs, T* __restrict__ pn, int R, int ntt,
                                                      TbPlan tp, int first, int last) {
   constexpr int W = 64 * V;

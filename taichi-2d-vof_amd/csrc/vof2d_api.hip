@@ -1000,6 +1000,60 @@ extern "C" int vof_debug_time_kernel(vof2d_handle h, int32_t which, int32_t abl,
   *avg_us = 1e3f * ms / (float)reps;
   return ensure_ok(h);
 }
+// Diagnostic build only (tools/probes/overlap_tail.py): what would it buy to let the NEXT step's k_jacobi_pair run in the slots
+// the tail of k_tm leaves empty?  `reps` times [k_tm, k_jacobi_pair] on the handle's current state, timing only (the Jacobi
+// launch reads the rhs the k_tm launch beside it is writing: wrong values, the state the steps run on is not touched):
+//   mode 0  both on one stream, one after the other (what the step does);
+//   mode 1  k_tm on a stream of the highest priority, k_jacobi_pair on one of the lowest, started together: the dispatcher
+//           should hand the Jacobi launch's workgroups only the slots k_tm's pending workgroups do not want;
+//   mode 2  the same without priorities (two plain streams);
+//   mode 3  the priorities the other way round.
+extern "C" int vof_debug_time_overlap(vof2d_handle h, int32_t mode, int32_t reps, float* avg_us) {
+  if (!h || !avg_us || reps < 1 || h->d.dtype != VOF_F64 || !buffer_stores_ok(h)) return VOF_EINVAL;
+  static hipStream_t sa = nullptr, sb = nullptr, sc = nullptr, sd = nullptr;
+  static hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+  if (!sa) {
+    int least = 0, greatest = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(h, hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, greatest));
+    HIPCHK(h, hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, least));
+    HIPCHK(h, hipStreamCreateWithFlags(&sc, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&sd, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] stream priorities: least %d, greatest %d\n", least, greatest);
+  }
+  hipStream_t const st = h->stream;
+  hipStream_t const s_tm = mode == 1 ? sa : mode == 3 ? sb : sc, s_j = mode == 1 ? sb : mode == 3 ? sa : sd;
+  HIPCHK(h, hipEventRecord(h->ev0, st));
+  for (int r = 0; r < reps; ++r) {
+    const bool yf = (r & 1) == 0;
+    if (mode == 0) {
+      if (yf) dbg_tm<true, 0>(h); else dbg_tm<false, 0>(h);
+      dbg_pair<0>(h, 0);
+      continue;
+    }
+    HIPCHK(h, hipEventRecord(e0, st));
+    HIPCHK(h, hipStreamWaitEvent(s_tm, e0, 0));
+    HIPCHK(h, hipStreamWaitEvent(s_j, e0, 0));
+    h->stream = s_tm;
+    if (yf) dbg_tm<true, 0>(h); else dbg_tm<false, 0>(h);
+    h->stream = s_j;
+    dbg_pair<0>(h, 0);
+    h->stream = st;
+    HIPCHK(h, hipEventRecord(ea, s_tm));
+    HIPCHK(h, hipEventRecord(eb, s_j));
+    HIPCHK(h, hipStreamWaitEvent(st, ea, 0));
+    HIPCHK(h, hipStreamWaitEvent(st, eb, 0));
+  }
+  HIPCHK(h, hipEventRecord(h->ev1, st));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_us = 1e3f * ms / (float)reps;
+  return ensure_ok(h);
+}
 #endif
 int vof_time_jacobi(vof2d_handle h, int32_t n, float* ms_per_sweep) {
   if (!h || !ms_per_sweep) return VOF_EINVAL;
@@ -1082,6 +1136,21 @@ int vof_comm_destroy(vof2d_handle h) {
   if (!h) return VOF_EINVAL;
   comm_teardown(h);
   return VOF_OK;
+}
+// a capture that failed after the fork may leave a communication stream inside the invalidated capture: the eager launches
+// that follow need working ones
+static bool comm_streams_usable_after_failed_capture(vof2d_ctx* h) {
+  for (hipStream_t* st : {&h->cstream}) {
+    if (!*st) continue;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(*st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      (void)hipStreamDestroy(*st);
+      *st = nullptr;
+      if (hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) return false;
+    }
+  }
+  return true;
 }
 static unsigned field_mask_ok(uint32_t mask) { return mask != 0 && (mask & ~127u) == 0; }
 int vof_comm_exchange(vof2d_handle h, uint32_t field_mask) {
@@ -1174,14 +1243,7 @@ static int step_exchange_mode5(vof2d_handle h, int64_t nsteps) {
         (void)hipGetLastError();
         h->gxchg5[key] = nullptr;
         h->xchg5_graph = 0;   // eager from here on
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(h->cstream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-          (void)hipGetLastError();
-          (void)hipStreamDestroy(h->cstream);
-          h->cstream = nullptr;
-          if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess)
-            return fail(h, VOF_EHIP, "cannot recreate the communication stream after a failed capture");
-        }
+        if (!comm_streams_usable_after_failed_capture(h)) return fail(h, VOF_EHIP, "cannot recreate the communication stream after a failed capture");
         if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] mode-5 exchange graph capture failed (%s): eager\n", hipGetErrorString(e));
       }
     }
@@ -1254,14 +1316,7 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
           (void)hipGetLastError();
           h->gxchg2[par][ori] = nullptr;
           h->xchg_pair = 0;   // single-step graphs from here on (they are known to work)
-          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-          if (hipStreamIsCapturing(h->cstream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-            (void)hipGetLastError();
-            (void)hipStreamDestroy(h->cstream);
-            h->cstream = nullptr;
-            if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess)
-              return fail(h, VOF_EHIP, "cannot recreate the communication stream after a failed capture");
-          }
+          if (!comm_streams_usable_after_failed_capture(h)) return fail(h, VOF_EHIP, "cannot recreate the communication stream after a failed capture");
           if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] two-step exchange graph capture failed (%s): one step per launch\n", hipGetErrorString(e));
         }
       }
@@ -1301,14 +1356,7 @@ int vof_step_exchange(vof2d_handle h, int64_t nsteps, int32_t overlap) {
           h->xchg_graph = 0;
           // a capture that failed after the fork may leave the communication stream inside the
           // invalidated capture: the eager launches below need a working one
-          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-          if (hipStreamIsCapturing(h->cstream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-            (void)hipGetLastError();
-            (void)hipStreamDestroy(h->cstream);
-            h->cstream = nullptr;
-            if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess)
-              return fail(h, VOF_EHIP, "cannot recreate the communication stream after a failed capture");
-          }
+          if (!comm_streams_usable_after_failed_capture(h)) return fail(h, VOF_EHIP, "cannot recreate the communication stream after a failed capture");
           if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] exchange graph capture failed (%s / %s): eager\n", hipGetErrorString(e), h->err);
         }
       }

@@ -52,6 +52,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cb["threads_1"]["cores"] == 1 and cb["threads_1"]["value"] > 0 and cb["jacobi_GBs_24B_rule"] > 0
     sus = d["sustained"]
     assert sus["steps"] == 200 and len(sus["ms_per_step_blocks"]) == 2 and sus["value"] > 0
+    wc = cfg["worst_case"]                         # the same grid holding the rising bubble (2 % gas): the spread of the step beside the headline
+    assert "-ic 2" in wc["workload"] and wc["ms_per_step"] > 0 and wc["steps"] >= 40
+    assert abs(wc["slowdown_vs_the_headline_workload"] - wc["ms_per_step"] / d["ms_per_step"]) < 1e-9
     for k in ("k_momentum", "k_jacobi_tb", "k_transport"):
         assert 0 < d["step_kernels"][k]["frac_of_peak"] < 1.5      # 512^2 sits in cache: may exceed the HBM figure
 
