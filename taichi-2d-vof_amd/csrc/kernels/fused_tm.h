@@ -23,8 +23,8 @@
 //     alternates the pairs.
 // Virtual ghosts (the steady-state fused step) only; on a strip the rows beyond its stored rows are the clamped edge rows (the invalid fringe).
 // The two marches below are k_transport's and k_momentum's row loops with the source / sink of F'', u, v exchanged (LDS
-// instead of memory) and the chunk bounds of the pair; they are kept as copies, not shared with the stand-alone kernels,
-// so that those kernels' register allocation and instruction schedule stay what profiles/ measured.
+// instead of memory) and the chunk bounds of the pair.  The arithmetic of a row is ONE source shared with the stand-alone
+// kernels (round 6): MomentumWindow::step (kernels/momentum.h), TransportRow (kernels/transport.h).
 #pragma once
 #include "momentum.h"
 #include "transport.h"
@@ -84,35 +84,22 @@ __device__ __forceinline__ void tm_transport_march(const Geom& g, const Consts<T
     return base + at(g, rc, j0);
   };
   const int tra = ma - 3, trb = mb + 3;
-  FctXPipe<T, V> pipe;
-  T p1[V], rho1[V];
+  // the register window and the arithmetic of an iteration are k_transport's (TransportWindow, kernels/transport.h): what differs
+  // here is where u, v and F'' go -- the pair's ring in LDS (and memory where somebody reads them) -- and the chunk bounds of the pair
+  TransportWindow<T, V> win;
   {
-    T f1[V];
+    T f1[V], pr1[V], v0[V];
     load_c<T, V>(f1, rowptr(F, tra - 3));
-    load_c<T, V>(p1, rowptr(p, tra - 3));
-#pragma unroll
-    for (int q = 0; q < V; ++q) rho1[q] = rho_of(c, f1[q]);
-    if (YFIRST && (IN || tra - 3 >= ilo)) {
-      T v0[V], fs[V];
+    load_c<T, V>(pr1, rowptr(p, tra - 3));
+    const bool swept = YFIRST && (IN || tra - 3 >= ilo);
+    if (swept) {
       load_s<T, V>(v0, rowptr(vs, tra - 3));
-      const T rhol = lane_up(rho1[V - 1]), pl = lane_up(p1[V - 1]);
-#pragma unroll
-      for (int q = 0; q < V; ++q) {
-        const int j = j0 + q;
-        const T vn = corrected_velocity<T>(c, v0[q], rho1[q], q == 0 ? rhol : rho1[q - 1], p1[q],
-                                           q == 0 ? pl : p1[q - 1], c.dyi);
-        v0[q] = (IN || (j >= 2 && j <= ny)) ? vn : (T)0;
-      }
-      fct_y_row<T, V, false, IN>(c, j0, ny, f1, v0, fs);
-      pipe.init(fs);
     } else {
-      pipe.init(f1);
-    }
-  }
-  int cls1 = 2;
-  T v1[V], v2[V], v3[V];
 #pragma unroll
-  for (int q = 0; q < V; ++q) v1[q] = v2[q] = v3[q] = (T)0;
+      for (int q = 0; q < V; ++q) v0[q] = (T)0;
+    }
+    win.template init<YFIRST, IN>(c, j0, ny, f1, pr1, v0, swept);
+  }
   T Fnx[V], usnx[V], vsnx[V], pnx[V];
   load_c<T, V>(Fnx, rowptr(F, tra - 2));
   load_s<T, V>(usnx, rowptr(us, tra - 2));
@@ -148,55 +135,9 @@ __device__ __forceinline__ void tm_transport_march(const Geom& g, const Consts<T
         wt_.barrier();
         continue;
       }
-      int cls = 2;
-      {
-        bool rz = true, ro = true;
-#pragma unroll
-        for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
-        if (__all(rz)) {
-          cls = 0;
-        } else {
-#pragma unroll
-          for (int q = 0; q < V; ++q) ro = ro && Fr[q] == (T)1;
-          if (__all(ro)) cls = 1;
-        }
-      }
-      {  // update_uv for row r (:269-280)
-        const T pl = lane_up(pr[V - 1]);
-        const bool urow = IN || (r >= 2 && r <= nx);
-        const bool own = r >= ma && r <= mb;
-        if (cls != 2 && cls == cls1) {
-          const T k = cls ? c.dt_rho_l : c.dt_rho_g;
-#pragma unroll
-          for (int q = 0; q < V; ++q) {
-            const int j = j0 + q;
-            const T un = ur[q] - k * (pr[q] - p1[q]) * c.dxi;
-            ur[q] = urow ? un : (T)0;
-            const T vn = vr[q] - k * (pr[q] - (q == 0 ? pl : pr[q - 1])) * c.dyi;
-            vr[q] = (IN || (j >= 2 && j <= ny)) ? vn : (T)0;
-            p1[q] = pr[q];
-          }
-        } else {
-          T rhor[V];
-          if (cls1 != 2) {
-#pragma unroll
-            for (int q = 0; q < V; ++q) rho1[q] = cls1 ? c.rho_l : c.rho_g;
-          }
-#pragma unroll
-          for (int q = 0; q < V; ++q) rhor[q] = rho_of(c, Fr[q]);
-          const T rhol = lane_up(rhor[V - 1]);
-#pragma unroll
-          for (int q = 0; q < V; ++q) {
-            const int j = j0 + q;
-            const T un = corrected_velocity<T>(c, ur[q], rhor[q], rho1[q], pr[q], p1[q], c.dxi);
-            ur[q] = urow ? un : (T)0;
-            const T vn = corrected_velocity<T>(c, vr[q], rhor[q], q == 0 ? rhol : rhor[q - 1], pr[q],
-                                               q == 0 ? pl : pr[q - 1], c.dyi);
-            vr[q] = (IN || (j >= 2 && j <= ny)) ? vn : (T)0;
-            p1[q] = pr[q];
-            rho1[q] = rhor[q];
-          }
-        }
+      T out[V];
+      const bool own = r >= ma && r <= mb;
+      win.template step<YFIRST, IN>(c, r, ilo, ihi, nx, j0, ny, Fr, ur, vr, pr, out, tra, trb, [&](bool urow) {
         if (own && (IN || (r >= g.own_lo && r <= g.own_hi))) {
 #pragma unroll
           for (int q = 0; q < V; ++q) {
@@ -224,35 +165,8 @@ __device__ __forceinline__ void tm_transport_march(const Geom& g, const Consts<T
             store_c<T, V>(Uo + at(g, r + 1, j0), zero, j0, jlo, jhi);
           }
         }
-        cls1 = cls;
-      }
-      T out[V];
-#pragma unroll
-      for (int q = 0; q < V; ++q) out[q] = (T)0;
+      });
       const int io = r - 3;
-      if (YFIRST) {
-        T Fp[V];
-        if ((!IN && (r < ilo || r > ihi)) || cls == 0) {
-#pragma unroll
-          for (int q = 0; q < V; ++q) Fp[q] = Fr[q];
-        } else {
-          fct_y_row<T, V, false, IN>(c, j0, ny, Fr, vr, Fp);
-        }
-        pipe.template push<true, IN>(c, r, ilo, ihi, Fp, ur, out, cls == 0);
-      } else {
-        T Fp[V];
-        pipe.template push<false, IN>(c, r, ilo, ihi, Fr, ur, Fp, cls == 0);   // F'[r-3]
-        if (io >= tra && io <= trb) {
-          bool rz = true;
-#pragma unroll
-          for (int q = 0; q < V; ++q) rz = rz && Fp[q] == (T)0;
-          if (!__all(rz)) fct_y_row<T, V, true, IN>(c, j0, ny, Fp, v3, out);
-        }
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          v3[q] = v2[q]; v2[q] = v1[q]; v1[q] = vr[q];
-        }
-      }
       ring_put<T, V>(ring.f[io & 7], lane, out);
       const bool st = io >= ma && io <= mb;
       if constexpr ((ABL & ABL_NO_STORE) != 0) {
@@ -289,7 +203,6 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
   const int ilo = g.ilo, ihi = g.ihi, nx = g.nx, ny = g.ny;
   const int jlo = IN ? c0 + HF : (c0 + HF > 1 ? c0 + HF : 1);
   const int jhi = IN ? c0 + W - HF - 1 : (c0 + W - HF - 1 < ny ? c0 + W - HF - 1 : ny);
-  const T dt = c.dt, dxi = c.dxi, dyi = c.dyi, dxi2 = c.dxi2, dyi2 = c.dyi2;
   bool dom[V];
 #pragma unroll
   for (int q = 0; q < V; ++q) dom[q] = IN || ((j0 + q) >= 1 && (j0 + q) <= ny);
@@ -298,47 +211,28 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
   auto get_F = [&](Row<T, V>& w, int r) { ring_get<T, V>(w, ring.f[mirrow(r) & 7], lane); };
   auto get_u = [&](Row<T, V>& w, int r) { ring_get<T, V>(w, ring.u[r & 7], lane); };
   auto get_v = [&](Row<T, V>& w, int r) { ring_get<T, V>(w, ring.v[mirrow(r) & 7], lane); };
-  Row<T, V> F2, F1;
-  T F3c[V];
-  Row<T, V> u3, u2, v3, v2;
-  T mx2[V], mx3[V], my2[V];
-  T k3[V];
-  T us3[V], vs3[V];
-  T rho3[V];
+  // the register window and the arithmetic of an iteration are k_momentum's (MomentumWindow, kernels/momentum.h): what differs
+  // here is where the rows come from -- the pair's ring in LDS -- and the chunk bounds of the pair
+  MomentumWindow<T, V> win;
+  win.init(c);
   const int r0 = ma - 1, r1 = mb + 3;
   const T* const us_tile = us_out + (int64_t)(g.col0 + c0);
   const T* const vs_tile = vs_out + (int64_t)(g.col0 + c0);
   const T* const rhs_tile = rhs + (int64_t)(g.col0 + c0);
   const int voff_st = (j0 >= jlo && j0 + V - 1 <= jhi) ? lane * (int)(V * sizeof(T)) : kBufSkip;
-  auto zero_row = [](Row<T, V>& w) {
-    w.l = w.r = (T)0;
-#pragma unroll
-    for (int q = 0; q < V; ++q) w.c[q] = (T)0;
-  };
-  zero_row(u3); zero_row(u2); zero_row(v3); zero_row(v2);
-  zero_row(F2); zero_row(F1);
-#pragma unroll
-  for (int q = 0; q < V; ++q) F3c[q] = mx2[q] = mx3[q] = my2[q] = k3[q] = us3[q] = vs3[q] = rho3[q] = (T)0;
-  bool flat2 = true, flat1 = true, flat0;
-  // Rows of uniform F (gas, or liquid away from the interface: nine rows in ten of a dam-break) -- wave-level history of
-  // `flat` (the three newest rows uniform and equal), bit k = the iteration k before this one.  What it lets a row skip is
-  // exact: the skipped arithmetic would produce the same zeros / the same rho, nu from the same F (round 6).
-  unsigned flat_hist = 0u;
-  // (the force terms of a flat window are +-0; they enter u*, v* as (... + gx) + fx: the sum in front is never -0 unless gx is)
-  const bool zero_force_ok = !(c.gx == (T)0 && __builtin_signbit(c.gx)) && !(c.gy == (T)0 && __builtin_signbit(c.gy));
   Row<T, V> un, vn;   // u / v row r-1 of the coming iteration
-  zero_row(un); zero_row(vn);
+  MomentumWindow<T, V>::zero_row(un); MomentumWindow<T, V>::zero_row(vn);
   for (int t = t_lo; t <= t_hi; ++t) {
     const int r = t - 5;
     if (r == r0) {   // the window's first two rows (k_momentum loads them in front of its loop)
-      get_F(F2, r0 - 2);
-      get_F(F1, r0 - 1);
+      Row<T, V> f2, f1;
+      get_F(f2, r0 - 2);
+      get_F(f1, r0 - 1);
       if (edge_cols) {
-        mirror_ghost_cols<T, V>(F2, j0, ny);
-        mirror_ghost_cols<T, V>(F1, j0, ny);
+        mirror_ghost_cols<T, V>(f2, j0, ny);
+        mirror_ghost_cols<T, V>(f1, j0, ny);
       }
-      flat2 = row_flat<T, V>(F2);
-      flat1 = row_flat<T, V>(F1);
+      win.set_F(f2, f1);
     }
     if (r >= r0 && r <= r1) {
       Row<T, V> F0, u1 = un;
@@ -350,161 +244,30 @@ __device__ __forceinline__ void tm_momentum_march(const Geom& g, const Consts<T>
         mirror_ghost_cols<T, V>(F0, j0, ny);
         mirror_ghost_cols<T, V>(u1, j0, ny);
       }
-      // ---- N: normals of row r-1 (:285-306)
-      const bool okN = IN || ((r - 1) >= ilo && (r - 1) <= ihi);
-      T mx1[V], my1[V];
-      flat0 = row_flat<T, V>(F0);
-      const bool flat = flat2 && flat1 && flat0 && F2.c[0] == F1.c[0] && F1.c[0] == F0.c[0];
-      const bool wflat = __all(flat);
-#ifdef VOF_NO_FLAT_SHORTCUTS      // (A/B builds: make variant NAME=noflat EXTRA=-DVOF_NO_FLAT_SHORTCUTS)
-      flat_hist = 0u;
-#else
-      flat_hist = __builtin_amdgcn_readfirstlane((flat_hist << 1) | (wflat ? 1u : 0u));
-#endif
-      if (wflat) {
-#pragma unroll
-        for (int q = 0; q < V; ++q) mx1[q] = my1[q] = (T)0;
-      } else {
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          T ox, oy;
-          normals_cell<T>(c, left_of(F2, q), F2.c[q], right_of(F2, q), left_of(F1, q), F1.c[q], right_of(F1, q),
-                          left_of(F0, q), F0.c[q], right_of(F0, q), ox, oy);
-          mx1[q] = (okN && dom[q]) ? ox : (T)0;
-          my1[q] = (okN && dom[q]) ? oy : (T)0;
+      const int i = r - 2, i3 = r - 3;
+      T out[V];
+      win.template step<IN, ABL>(c, r, ilo, ihi, j0, ny, dom, F0, u1, v1, out, BS || (i3 >= ma && i3 <= mb), [&](const T (&us2)[V], const T (&vs2)[V]) {
+        if constexpr ((ABL & ABL_NO_STORE) != 0) {
+          asm volatile("" :: "v"(us2[0]), "v"(us2[V - 1]), "v"(vs2[0]), "v"(vs2[V - 1]));
+        } else if constexpr (BS) {
+          const bool rowok = i >= ma && i <= mb;
+          const int vo = rowok ? voff_st : kBufSkip;
+          const int so = rowok ? (int)((int64_t)(i - g.row_lo) * g.pitch * (int64_t)sizeof(T)) : 0;
+          store_buf_nt<T, V>(us_tile, vo, so, us2);
+          store_buf_nt<T, V>(vs_tile, vo, so, vs2);
+        } else if (i >= ma && i <= mb) {
+          if (i >= 2) store_s<T, V>(us_out + at(g, i, j0), us2, j0, jlo, jhi);
+          store_s<T, V>(vs_out + at(g, i, j0), vs2, j0, jlo > 2 ? jlo : 2, jhi);
         }
-      }
-      // ---- K: kappa of row r-2 (:307-309)
-      const bool okK = IN || ((r - 2) >= ilo && (r - 2) <= ihi);
-      T k2[V];
-      if ((flat_hist & 7u) == 7u) {
-        // flat for three iterations: mx1, mx3 and every my2 of the wave are the +0 the flat branch above assigned
-        const T kk = -(c.kap_x * ((T)0 - (T)0) + c.kap_y * ((T)0 - (T)0));
-#pragma unroll
-        for (int q = 0; q < V; ++q) k2[q] = (okK && dom[q]) ? kk : (T)0;
-      } else {
-        const T myl = lane_up(my2[V - 1]), myr = lane_dn(my2[0]);
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          const T yr = q == V - 1 ? myr : my2[q + 1], yl = q == 0 ? myl : my2[q - 1];
-          const T kk = -(c.kap_x * (mx1[q] - mx3[q]) + c.kap_y * (yr - yl));
-          k2[q] = (okK && dom[q]) ? kk : (T)0;
-        }
-      }
-      // ---- P: u*, v* of row i = r-2 (:206-233)
-      const int i = r - 2;
-      const bool okP = IN || (i >= ilo && i <= ihi);
-      T us2[V], vs2[V], rho2[V], nu2[V];
-      T rho2l;
-      if ((flat_hist & 3u) != 0u) {   // row r-2 is uniform (it belongs to a flat window): one rho, one nu
-        const T rf = rho_of(c, F2.c[0]), nf = nu_of(c, F2.c[0]);
-#pragma unroll
-        for (int q = 0; q < V; ++q) { rho2[q] = rf; nu2[q] = nf; }
-        rho2l = rf;
-      } else {
-#pragma unroll
-        for (int q = 0; q < V; ++q) { rho2[q] = rho_of(c, F2.c[q]); nu2[q] = nu_of(c, F2.c[q]); }
-        rho2l = rho_of(c, F2.l);
-      }
-      T fxf[V], fyf[V];
-      bool any_force = false;
-      if ((flat_hist & 2u) != 0u && zero_force_ok) {
-        // rows r-3, r-2 (and r-1) uniform and equal: F00 - Fm0 and F00 - F0m are +0, the force numerators +-0 whatever kappa is
-#pragma unroll
-        for (int q = 0; q < V; ++q) fxf[q] = fyf[q] = (T)0;
-      } else {
-        const T kl = lane_up(k2[V - 1]);
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          const T F00 = F2.c[q], Fm0 = F3c[q], F0m = left_of(F2, q);
-          const T k00 = k2[q], km0 = k3[q], k0m = q == 0 ? kl : k2[q - 1];
-          fxf[q] = -c.sigma * (F00 - Fm0) * ((k00 + km0) / (T)2.0);
-          fyf[q] = -c.sigma * (F00 - F0m) * ((k00 + k0m) / (T)2.0);
-          any_force = any_force || fxf[q] != (T)0 || fyf[q] != (T)0;
-        }
-      }
-      if (any_force) {
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          const T rho00 = rho2[q], rhom0 = rho3[q], rho0m = q == 0 ? rho2l : rho2[q - 1];
-          const T fnum[2] = {fxf[q], fyf[q]}, fden[2] = {c.dx, c.dy}, finv[2] = {c.inv_dx, c.inv_dy};
-          T fk[2];
-          div_by_const_v<T, 2, true>(fk, fnum, fden, finv);
-          fxf[q] = div_or_zero<T>(fk[0] * (T)2, rho00 + rhom0);
-          fyf[q] = div_or_zero<T>(fk[1] * (T)2, rho00 + rho0m);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < V; ++q) {
-        const T u00 = u2.c[q], um0 = u3.c[q], up0 = u1.c[q], u0m = left_of(u2, q), u0p = right_of(u2, q);
-        const T upm = left_of(u1, q);
-        const T v00 = v2.c[q], vm0 = v3.c[q], vp0 = v1.c[q], v0m = left_of(v2, q), v0p = right_of(v2, q);
-        const T vmp = right_of(v3, q);
-        const T nu00 = nu2[q];
-        T ou, ov;
-        {
-          T v_here = (T)0.25 * (vm0 + vmp + v00 + v0p);
-          T dudx = upwind_diff<T>(u00 > 0, u00, um0, up0) * dxi;
-          T dudy = upwind_diff<T>(v_here > 0, u00, u0m, u0p) * dyi;
-          ou = (u00 + dt * (nu00 * (um0 - (T)2 * u00 + up0) * dxi2 + nu00 * (u0m - (T)2 * u00 + u0p) * dyi2 -
-                            u00 * dudx - v_here * dudy + c.gx + fxf[q]));
-          if constexpr ((ABL & ABL_NO_UPRED) != 0) ou = u00 + dt * (um0 + c.gx + fxf[q]);   // (timing only)
-        }
-        {
-          T u_here = (T)0.25 * (u0m + u00 + upm + up0);
-          T dvdx = upwind_diff<T>(u_here > 0, v00, vm0, vp0) * dxi;
-          T dvdy = upwind_diff<T>(v00 > 0, v00, v0m, v0p) * dyi;
-          ov = (v00 + dt * (nu00 * (vm0 - (T)2 * v00 + vp0) * dxi2 + nu00 * (v0m - (T)2 * v00 + v0p) * dyi2 -
-                            u_here * dvdx - v00 * dvdy + c.gy + fyf[q]));
-          if constexpr ((ABL & ABL_NO_VPRED) != 0) ov = v00 + dt * (vm0 + c.gy + fyf[q]);   // (timing only)
-        }
-        const int j = j0 + q;
-        us2[q] = (okP && (IN || i >= 2) && dom[q]) ? ou : (T)0;
-        vs2[q] = (okP && (IN || (j >= 2 && j <= ny))) ? ov : (T)0;
-      }
+      });
       if constexpr ((ABL & ABL_NO_STORE) != 0) {
-        asm volatile("" :: "v"(us2[0]), "v"(us2[V - 1]), "v"(vs2[0]), "v"(vs2[V - 1]));
+        if (BS || (i3 >= ma && i3 <= mb)) asm volatile("" :: "v"(out[0]), "v"(out[V - 1]));
       } else if constexpr (BS) {
-        const bool rowok = i >= ma && i <= mb;
-        const int vo = rowok ? voff_st : kBufSkip;
-        const int so = rowok ? (int)((int64_t)(i - g.row_lo) * g.pitch * (int64_t)sizeof(T)) : 0;
-        store_buf_nt<T, V>(us_tile, vo, so, us2);
-        store_buf_nt<T, V>(vs_tile, vo, so, vs2);
-      } else if (i >= ma && i <= mb) {
-        if (i >= 2) store_s<T, V>(us_out + at(g, i, j0), us2, j0, jlo, jhi);
-        store_s<T, V>(vs_out + at(g, i, j0), vs2, j0, jlo > 2 ? jlo : 2, jhi);
+        store_buf_nt<T, V>(rhs_tile, (i3 >= ma && i3 <= mb) ? voff_st : kBufSkip,
+                           (i3 >= ma && i3 <= mb) ? (int)((int64_t)(i3 - g.row_lo) * g.pitch * (int64_t)sizeof(T)) : 0, out);
+      } else if (i3 >= ma && i3 <= mb) {
+        store_s<T, V>(rhs + at(g, i3, j0), out, j0, jlo, jhi);
       }
-      // ---- R: rhs of row r-3 (:239-241)
-      const int i3 = r - 3;
-      if (BS || (i3 >= ma && i3 <= mb)) {
-        const T vsr = lane_dn(vs3[0]);
-        T out[V];
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          const T vright = q == V - 1 ? vsr : vs3[q + 1];
-          out[q] = div_by_const_inrange<T>(rho3[q], c.dt, c.inv_dt) *
-                   ((us2[q] - us3[q]) * c.dxi + (vright - vs3[q]) * c.dyi);
-        }
-        if constexpr ((ABL & ABL_NO_STORE) != 0)
-          asm volatile("" :: "v"(out[0]), "v"(out[V - 1]));
-        else if constexpr (BS)
-          store_buf_nt<T, V>(rhs_tile, (i3 >= ma && i3 <= mb) ? voff_st : kBufSkip,
-                             (i3 >= ma && i3 <= mb) ? (int)((int64_t)(i3 - g.row_lo) * g.pitch * (int64_t)sizeof(T)) : 0, out);
-        else
-          store_s<T, V>(rhs + at(g, i3, j0), out, j0, jlo, jhi);
-      }
-#pragma unroll
-      for (int q = 0; q < V; ++q) {
-        F3c[q] = F2.c[q];
-        mx3[q] = mx2[q]; mx2[q] = mx1[q]; my2[q] = my1[q];
-        k3[q] = k2[q];
-        us3[q] = us2[q]; vs3[q] = vs2[q];
-        rho3[q] = rho2[q];
-      }
-      F2 = F1; F1 = F0;
-      flat2 = flat1; flat1 = flat0;
-      u3 = u2; u2 = u1;
-      v3 = v2; v2 = v1;
     }
     wt_.barrier();
   }

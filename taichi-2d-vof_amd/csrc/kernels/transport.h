@@ -234,6 +234,140 @@ struct FctXPipe {
   }
 };
 
+// ------------------------------------------------------------------ one row of the fused transport, shared by k_transport and k_tm
+// update_uv (2dvof.py:269-280) of the newest row and both FCT sweeps of solve_VOF_rudman (:312-318) as one iteration of a march
+// along i: rows r of F, u*, v*, p come in, u and v of row r come out (through `on_uv`: a store, or k_tm's ring in LDS) and F'' of
+// row r - 3.  The y sweep is row-local: a per-row stage in front of the x pipeline (YFIRST, even steps) or behind it.  Where the rows
+// come from and go to, and which rows a chunk owns, is the caller's business -- one source for the arithmetic (round 6).
+//   IN (an interior pair of k_tm): every row the march touches lies strictly inside [ilo, ihi] and every column in [2, ny].
+template <typename T, int V>
+struct TransportWindow {
+  FctXPipe<T, V> pipe;
+  T p1[V], rho1[V];        // p and rho of the previous row (update_uv's i-1 operands)
+  int cls1;                // class of the previous row (see step); 2: rho1 holds the row's densities lane by lane
+  T v1[V], v2[V], v3[V];   // x first: corrected v of rows r-1, r-2, r-3 (the y sweep trails the pipeline)
+
+  // f1, pr1, v0: rows (first row of the march - 1) of F, p and v* -- the pipeline's first donor row.  YFIRST: that row enters the
+  // pipeline y-swept (its corrected v needs operands of the same row only) unless it lies outside [ilo, ihi]
+  template <bool YFIRST, bool IN>
+  __device__ __forceinline__ void init(const Consts<T>& c, int j0, int ny, const T (&f1)[V], const T (&pr1)[V], const T (&v0)[V], bool swept) {
+#pragma unroll
+    for (int q = 0; q < V; ++q) { p1[q] = pr1[q]; rho1[q] = rho_of(c, f1[q]); }
+    if (YFIRST && swept) {
+      T vv[V], fs[V];
+      const T rhol = lane_up(rho1[V - 1]), pl = lane_up(p1[V - 1]);
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const int j = j0 + q;
+        const T vn = corrected_velocity<T>(c, v0[q], rho1[q], q == 0 ? rhol : rho1[q - 1], p1[q],
+                                           q == 0 ? pl : p1[q - 1], c.dyi);
+        vv[q] = (IN || (j >= 2 && j <= ny)) ? vn : (T)0;
+      }
+      fct_y_row<T, V, false, IN>(c, j0, ny, f1, vv, fs);
+      pipe.init(fs);
+    } else {
+      pipe.init(f1);
+    }
+    cls1 = 2;
+#pragma unroll
+    for (int q = 0; q < V; ++q) v1[q] = v2[q] = v3[q] = (T)0;
+  }
+
+  // Fr, ur, vr, pr: rows r of F, u*, v*, p (ur / vr become u / v of the row); out: F'' of row r - 3.  [ylo, yhi]: the rows whose
+  // trailing y sweep (x first) this chunk needs.  on_uv(cls) is called when u and v of the row exist.
+  template <bool YFIRST, bool IN, typename OnUV>
+  __device__ __forceinline__ void step(const Consts<T>& c, int r, int ilo, int ihi, int nx, int j0, int ny, const T (&Fr)[V], T (&ur)[V],
+                                       T (&vr)[V], const T (&pr)[V], T (&out)[V], int ylo, int yhi, OnUV&& on_uv) {
+    // Class of the row as the wave sees it (wave-uniform): 0 = F is an exact 0 on every lane (gas), 1 = an exact 1
+    // (liquid), 2 = anything else.  In a class-0 / class-1 row rho is rho_g / rho_l on every lane (rho_of(0) =
+    // rho_g * 1 + rho_l * 0, rho_of(1) = rho_g * 0 + rho_l * 1: exact), and when the row below has the same class
+    // update_uv's r = (rho + rho') / 2 is that density and dt / r the host's correctly rounded dt / rho.
+    int cls = 2;
+    {
+      bool rz = true, ro = true;
+#pragma unroll
+      for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
+      if (__all(rz)) {
+        cls = 0;
+      } else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) ro = ro && Fr[q] == (T)1;
+        if (__all(ro)) cls = 1;
+      }
+    }
+    {  // update_uv for row r (:269-280): ur / vr hold u*[r] / v*[r]
+      const T pl = lane_up(pr[V - 1]);
+      const bool urow = IN || (r >= 2 && r <= nx);     // u exists on i in [2, nx]; the walls keep 0
+      VOF_STAT(3);
+      if (cls == 0) VOF_STAT(4);
+      if (cls == 1) VOF_STAT(5);
+      if (cls != 2 && cls == cls1) {
+        VOF_STAT(6);
+        const T k = cls ? c.dt_rho_l : c.dt_rho_g;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          const int j = j0 + q;
+          const T un = ur[q] - k * (pr[q] - p1[q]) * c.dxi;
+          ur[q] = urow ? un : (T)0;
+          const T vn = vr[q] - k * (pr[q] - (q == 0 ? pl : pr[q - 1])) * c.dyi;
+          vr[q] = (IN || (j >= 2 && j <= ny)) ? vn : (T)0;
+          p1[q] = pr[q];
+        }
+      } else {
+        T rhor[V];
+        if (cls1 != 2) {   // the row below went through the branch above: its densities are the constant
+#pragma unroll
+          for (int q = 0; q < V; ++q) rho1[q] = cls1 ? c.rho_l : c.rho_g;
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) rhor[q] = rho_of(c, Fr[q]);
+        const T rhol = lane_up(rhor[V - 1]);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          const int j = j0 + q;
+          const T un = corrected_velocity<T>(c, ur[q], rhor[q], rho1[q], pr[q], p1[q], c.dxi);
+          ur[q] = urow ? un : (T)0;
+          const T vn = corrected_velocity<T>(c, vr[q], rhor[q], q == 0 ? rhol : rhor[q - 1], pr[q],
+                                             q == 0 ? pl : pr[q - 1], c.dyi);
+          vr[q] = (IN || (j >= 2 && j <= ny)) ? vn : (T)0;   // v exists on j in [2, ny]; j = 1, ny+1 keep set_BC's 0
+          p1[q] = pr[q];
+          rho1[q] = rhor[q];
+        }
+      }
+      on_uv(urow);
+      cls1 = cls;
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) out[q] = (T)0;
+    const int io = r - 3;
+    if (YFIRST) {
+      // y sweep of row r in front of the pipeline; rows outside [ilo, ihi] (the ghost rows) enter
+      // unswept, which is what the twin buffer holds for the x sweep in the two-kernel form
+      T Fp[V];
+      if ((!IN && (r < ilo || r > ihi)) || cls == 0) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) Fp[q] = Fr[q];
+      } else {
+        fct_y_row<T, V, false, IN>(c, j0, ny, Fr, vr, Fp);
+      }
+      pipe.template push<true, IN>(c, r, ilo, ihi, Fp, ur, out, cls == 0);
+    } else {
+      T Fp[V];
+      pipe.template push<false, IN>(c, r, ilo, ihi, Fr, ur, Fp, cls == 0);   // F'[r-3]
+      if (io >= ylo && io <= yhi) {
+        bool rz = true;
+#pragma unroll
+        for (int q = 0; q < V; ++q) rz = rz && Fp[q] == (T)0;
+        if (!__all(rz)) fct_y_row<T, V, true, IN>(c, j0, ny, Fp, v3, out);
+      }
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        v3[q] = v2[q]; v2[q] = v1[q]; v1[q] = vr[q];
+      }
+    }
+  }
+};
+
 // CORR (full-domain handles only): the sweep that runs first also performs update_uv -- it
 // computes u and v from u*, v*, p and F (rho) for the rows it streams, stores them, and feeds its
 // own component straight into the flux pipeline.  `u` is then an output (Uo) and the wall faces
@@ -528,37 +662,21 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
     const int rc = r < g.row_lo ? g.row_lo : (r > g.row_hi ? g.row_hi : r);
     return base + at(g, rc, j0);
   };
-  FctXPipe<T, V> pipe;
-  T p1[V], rho1[V];   // p and rho of the previous row (update_uv's i-1 operands)
+  // the register window and the arithmetic of an iteration: TransportWindow (shared with k_tm)
+  TransportWindow<T, V> win;
   {
-    T f1[V];
+    T f1[V], pr1[V], v0[V];
     load_c<T, V>(f1, rowptr(F, ra - 3));
-    load_c<T, V>(p1, rowptr(p, ra - 3));
-#pragma unroll
-    for (int q = 0; q < V; ++q) rho1[q] = rho_of(c, f1[q]);
-    if (YFIRST && ra - 3 >= ilo) {
-      // the pipeline's first donor cell is row ra-3 of the y-swept F: sweep that row here (its
-      // corrected v needs operands of the same row only)
-      T v0[V], fs[V];
+    load_c<T, V>(pr1, rowptr(p, ra - 3));
+    const bool swept = YFIRST && ra - 3 >= ilo;
+    if (swept) {
       load_s<T, V>(v0, rowptr(vs, ra - 3));
-      const T rhol = lane_up(rho1[V - 1]), pl = lane_up(p1[V - 1]);
-#pragma unroll
-      for (int q = 0; q < V; ++q) {
-        const int j = j0 + q;
-        const T vn = corrected_velocity<T>(c, v0[q], rho1[q], q == 0 ? rhol : rho1[q - 1], p1[q],
-                                           q == 0 ? pl : p1[q - 1], c.dyi);
-        v0[q] = (j >= 2 && j <= ny) ? vn : (T)0;
-      }
-      fct_y_row<T, V, false>(c, j0, ny, f1, v0, fs);
-      pipe.init(fs);
     } else {
-      pipe.init(f1);
-    }
-  }
-  int cls1 = 2;           // class of the previous row (see the loop); 2: rho1 holds the row's densities lane by lane
-  T v1[V], v2[V], v3[V];  // x first: corrected v of rows r-1, r-2, r-3 (the y sweep trails the pipeline)
 #pragma unroll
-  for (int q = 0; q < V; ++q) v1[q] = v2[q] = v3[q] = (T)0;
+      for (int q = 0; q < V; ++q) v0[q] = (T)0;
+    }
+    win.template init<YFIRST, false>(c, j0, ny, f1, pr1, v0, swept);
+  }
   T Fnx[V], usnx[V], vsnx[V], pnx[V];  // row r, prefetched one iteration ahead
   load_c<T, V>(Fnx, rowptr(F, ra - 2));
   load_s<T, V>(usnx, rowptr(us, ra - 2));
@@ -584,63 +702,9 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
       if (YFIRST || (r + 1 >= ra && r + 1 <= rb)) load_s<T, V>(vsnx, rowptr(vs, r + 1));
       load_c<T, V>(pnx, rowptr(p, r + 1));
     }
-    // Class of the row as the wave sees it (wave-uniform): 0 = F is an exact 0 on every lane (gas), 1 = an exact 1
-    // (liquid), 2 = anything else.  In a class-0 / class-1 row rho is rho_g / rho_l on every lane (rho_of(0) =
-    // rho_g * 1 + rho_l * 0, rho_of(1) = rho_g * 0 + rho_l * 1: exact), and when the row below has the same class
-    // update_uv's r = (rho + rho') / 2 is that density and dt / r the host's correctly rounded dt / rho.
-    int cls = 2;
-    {
-      bool rz = true, ro = true;
-#pragma unroll
-      for (int q = 0; q < V; ++q) rz = rz && Fr[q] == (T)0;
-      if (__all(rz)) {
-        cls = 0;
-      } else {
-#pragma unroll
-        for (int q = 0; q < V; ++q) ro = ro && Fr[q] == (T)1;
-        if (__all(ro)) cls = 1;
-      }
-    }
-    {  // update_uv for row r (:269-280): ur / vr hold u*[r] / v*[r]
-      const T pl = lane_up(pr[V - 1]);
-      const bool urow = r >= 2 && r <= nx;     // u exists on i in [2, nx]; the walls keep 0
-      const bool own = r >= ra && r <= rb;     // rows this chunk stores (and counts)
-      VOF_STAT(3);
-      if (cls == 0) VOF_STAT(4);
-      if (cls == 1) VOF_STAT(5);
-      if (cls != 2 && cls == cls1) {
-        VOF_STAT(6);
-        const T k = cls ? c.dt_rho_l : c.dt_rho_g;
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          const int j = j0 + q;
-          const T un = ur[q] - k * (pr[q] - p1[q]) * c.dxi;
-          ur[q] = urow ? un : (T)0;
-          const T vn = vr[q] - k * (pr[q] - (q == 0 ? pl : pr[q - 1])) * c.dyi;
-          vr[q] = (j >= 2 && j <= ny) ? vn : (T)0;
-          p1[q] = pr[q];
-        }
-      } else {
-        T rhor[V];
-        if (cls1 != 2) {   // the row below went through the branch above: its densities are the constant
-#pragma unroll
-          for (int q = 0; q < V; ++q) rho1[q] = cls1 ? c.rho_l : c.rho_g;
-        }
-#pragma unroll
-        for (int q = 0; q < V; ++q) rhor[q] = rho_of(c, Fr[q]);
-        const T rhol = lane_up(rhor[V - 1]);
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          const int j = j0 + q;
-          const T un = corrected_velocity<T>(c, ur[q], rhor[q], rho1[q], pr[q], p1[q], c.dxi);
-          ur[q] = urow ? un : (T)0;
-          const T vn = corrected_velocity<T>(c, vr[q], rhor[q], q == 0 ? rhol : rhor[q - 1], pr[q],
-                                             q == 0 ? pl : pr[q - 1], c.dyi);
-          vr[q] = (j >= 2 && j <= ny) ? vn : (T)0;   // v exists on j in [2, ny]; j = 1, ny+1 keep set_BC's 0
-          p1[q] = pr[q];
-          rho1[q] = rhor[q];
-        }
-      }
+    T out[V];
+    const bool own = r >= ra && r <= rb;     // rows this chunk stores (and counts)
+    win.template step<YFIRST, false>(c, r, ilo, ihi, nx, j0, ny, Fr, ur, vr, pr, out, ra, rb, [&](bool urow) {
       if (own && r >= g.own_lo && r <= g.own_hi) {
 #pragma unroll
         for (int q = 0; q < V; ++q) {
@@ -661,40 +725,8 @@ __global__ __launch_bounds__(256) void k_transport(Geom g, Consts<T> c, const T*
           store_c<T, V>(Uo + at(g, r + 1, j0), zero, j0, jlo, jhi);
         }
       }
-      cls1 = cls;
-    }
-    T out[V];
+    });
     const int io = r - 3;
-    if (YFIRST) {
-      // y sweep of row r in front of the pipeline; rows outside [ilo, ihi] (the ghost rows) enter
-      // unswept, which is what the twin buffer holds for the x sweep in the two-kernel form
-      T Fp[V];
-      if (r < ilo || r > ihi || cls == 0) {
-#pragma unroll
-        for (int q = 0; q < V; ++q) Fp[q] = Fr[q];
-      } else {
-        fct_y_row<T, V, false>(c, j0, ny, Fr, vr, Fp);
-      }
-      pipe.template push<true>(c, r, ilo, ihi, Fp, ur, out, cls == 0);
-    } else {
-      T Fp[V];
-      pipe.template push<false>(c, r, ilo, ihi, Fr, ur, Fp, cls == 0);   // F'[r-3]
-      if (io >= ra && io <= rb) {
-        bool rz = true;
-#pragma unroll
-        for (int q = 0; q < V; ++q) rz = rz && Fp[q] == (T)0;
-        if (__all(rz)) {
-#pragma unroll
-          for (int q = 0; q < V; ++q) out[q] = (T)0;
-        } else {
-          fct_y_row<T, V, true>(c, j0, ny, Fp, v3, out);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < V; ++q) {
-        v3[q] = v2[q]; v2[q] = v1[q]; v1[q] = vr[q];
-      }
-    }
     if (io >= ra && io <= rb) store_s<T, V>(Fn + at(g, io, j0), out, j0, jlo, jhi);
   }
   if (__any(viol != 0)) {
