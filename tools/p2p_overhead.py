@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--n", type=int, default=8); ap.add_argument("--nx", type=int, default=8192)
     ap.add_argument("--ny", type=int, default=8192); ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--dt", type=float, default=1e-6)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--modes", default="compute,native-overlap,native-two,native-after,native-fused,compute-pairs,native-pairs")
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--param", action="append", default=[], help="knob=value set on the strip's handle (e.g. tm_rows=52)")
@@ -42,7 +43,7 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         stream = torch.cuda.Stream()
         stream_ptr = stream.cuda_stream
-    e = Engine(api, make_desc(api, a.nx, a.ny, "f64", "f32", rows=rows, own=own, device=0, dt=a.dt), stream=stream_ptr)
+    e = Engine(api, make_desc(api, a.nx, a.ny, a.dtype, "f32", rows=rows, own=own, device=0, dt=a.dt), stream=stream_ptr)
     for kv in a.param:
         e.set_param(kv.split("=")[0], float(kv.split("=")[1]))
     e.set_init_F(1)
@@ -54,7 +55,7 @@ def main():
         views = {}
         for f in ("F", "u", "v", "p"):
             base, pitch, col0, nrows = e.field_view(f)
-            views[f] = torch.as_tensor(_DevArray(base, (nrows, pitch), "<f8"), device="cuda:0")
+            views[f] = torch.as_tensor(_DevArray(base, (nrows, pitch), "<f8" if a.dtype == "f64" else "<f4"), device="cuda:0")
 
         def ops_for(f):
             t = views[f]
@@ -96,7 +97,7 @@ def main():
                     for x in w:
                         x.wait()
 
-    print("strip %s of %dx%d (own %s), W=%d, %d KiB per field and edge" % (rows, a.nx, a.ny, own, W, W * e.field_view("F")[1] * 8 // 1024))
+    print("strip %s of %dx%d (own %s), W=%d, %d KiB per field and edge" % (rows, a.nx, a.ny, own, W, W * e.field_view("F")[1] * (8 if a.dtype == "f64" else 4) // 1024))
     for rnd in range(a.rounds):
         for mode in modes:
             run(mode, 10); e.sync()
