@@ -887,6 +887,32 @@ def test_k_tm_batches_chain_across_calls(hip_api, oracle_api, dtype, ic, nx, ny)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ic,gx,gy,sigma", [("f64", 1, 0.0, -5.0, 0.007), ("f64", 3, -0.0, -5.0, 0.007), ("f32", 2, -0.0, -0.0, 0.007),
+                                                 ("f64", 2, 3.0, 0.0, 0.0), ("f32", 1, 0.0, -5.0, -0.02)])
+def test_flat_window_shortcuts_change_no_value(hip_api, oracle_api, dtype, ic, gx, gy, sigma):
+    """The momentum march (MomentumWindow::step, shared by k_momentum and k_tm) skips, on rows whose F window has been uniform
+    for one / two / three iterations, all but one rho / nu, the force numerators and kappa -- exact by construction: the skipped
+    arithmetic yields the same zeros, which enter u*, v* behind `+ gx`, `+ gy`.  Dam-break, drop and bubble (flat gas and flat
+    liquid), both batch forms and the plain sequence against the oracle, also with gx / gy = -0.0 (where a -0 force numerator
+    WOULD be observable: the shortcut switches itself off), with sigma = 0 and with a negative sigma."""
+    n = 256
+    kw = dict(gx=gx, gy=gy, sigma=sigma)
+    a = engine(hip_api, n, n, dtype, "f32", ic=ic, **kw)
+    a.set_param("overlap_halves", 0)
+    a.set_param("fuse_tm", 1)
+    b = engine(hip_api, n, n, dtype, "f32", ic=ic, **kw)
+    b.set_param("overlap_halves", 0)
+    b.set_param("fuse_tm", 0)
+    o = engine(oracle_api, n, n, dtype, "f32", ic=ic, **kw)
+    for st in (1, 2, 9, 40, 41, 120):
+        for e in (a, b, o):
+            e.step(st - e.istep)
+        assert_fields_same(a, o, STATE + ("u_star", "v_star", "rhs"), ctx="k_tm form / oracle, %s ic %d g (%r, %r) sigma %g step %d" % (dtype, ic, gx, gy, sigma, st))
+        assert_fields_same(b, o, STATE + ("u_star", "v_star", "rhs"), ctx="plain sequence / oracle, %s ic %d g (%r, %r) sigma %g step %d" % (dtype, ic, gx, gy, sigma, st))
+    assert a.get_counter("tm_steps") >= 100 and b.get_counter("tm_steps") == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,iters", [("f64", 20), ("f32", 30), ("f64", 15)])
 def test_strip_pieces_run_every_sweep(hip_api, oracle_api, dtype, iters):
     """A middle step of overlap mode 5 (vof_step_tm_piece(1): tm5_jacobi + k_tm) runs jacobi_iters sweeps -- jacobi_iters / 10
