@@ -111,7 +111,7 @@ int vof_post_process_f(vof2d_handle h);             /* :452-455 */
  * set_field / a single verb runs eagerly with the intermediate boundary launches the reference's
  * :518 / :525 stand for; steady-state steps are replayed in batches of 16 / 8 / 2 per graph launch, as chains of
  * launches on row blocks); large grids (either precision: from 4 M cells on where at least half of the cells are
- * gas, from 20 M cells on whatever they hold -- a rule on the state, looked at once per handle and initial state) run two launches per step --
+ * gas, from 16 M cells on whatever they hold, in fp32 also below 6 M -- a rule on the state, looked at once per handle and initial state) run two launches per step --
  * k_jacobi_pair (ten sweeps) and k_tm (the step's transport + the next step's momentum), DESIGN.md 3.5 / 3.6 -- in
  * batches of 32 / 8 / 2 that chain.  Whatever the form, F u v p u_star v_star rhs read back after n steps are the
  * reference's after n steps.  rho / nu / mx / my / kappa scratch is not materialised (the k_tm form uses mx, my,

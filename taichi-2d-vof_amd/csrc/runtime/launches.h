@@ -119,10 +119,11 @@ inline bool buffer_stores_ok(const vof2d_ctx* h) {
 }
 
 // ------------------------------------------------------------------ launches
-// From this many cells on a full domain runs the pair kernels whatever it holds (the rule of vof_step, runtime/schedule.h):
-// bubble (2 % gas) fp64 4096^2 0.58-0.64 against 0.61-0.64 ms/step for the chains (a tie), 5120^2 0.78-0.83 / 0.89-0.92,
-// 8192^2 1.67-1.71 / 2.17-2.20; fp32 3072^2 0.257-0.280 / 0.252-0.265, 4096^2 0.366-0.403 / 0.371-0.396
-constexpr long kTmAlwaysCells = 20000000L;
+// From this many cells on a full domain runs the pair kernels whatever it holds (the rule of vof_step, runtime/schedule.h).  Re-measured
+// with the kernels of round 6 (profiles/r06_forms_sweep.txt, ms/step pairs / chains on the rising bubble, 2 % gas): fp64 2048^2 0.253 / 0.227,
+// 2560^2 0.325 / 0.312, 3072^2 0.405 / 0.411, 4096^2 0.592 / 0.614; fp32 2560^2 0.199 / 0.190, 3072^2 0.246 / 0.243, 4096^2 0.352 / 0.365
+// (round 5, before the branch-free division tier: ties at 4096^2, hence 20 M then); 5120^2 0.78-0.83 / 0.89-0.92, 8192^2 1.67-1.71 / 2.17-2.20
+constexpr long kTmAlwaysCells = 16000000L;
 constexpr long kTbPlanWaves = 16384;   // waves of a k_jacobi_tb launch the work plan can describe
 enum KernelId { kMomentum = 0, kSetBC, kJacobi, kJacobiTB, kCorrect, kFctX, kFctY, kNormals, kKappa, kPredictor,
                 kRhs, kOther, kTransport, kJacobiPair, kTM, kTMUV, NKERNELS };

@@ -216,6 +216,14 @@ inline bool tm_eligible(const vof2d_ctx* h) {
 // a rule on the state (fuse_tm = -1, the default: decide_batch_form_by_rule) or, for exploration, by timing both (fuse_tm = -2).
 constexpr double kTmGasShare = 0.5;   // k_tm from this share of exact-zero cells of F on
 // ... and on grids of kTmAlwaysCells and more whatever they hold (runtime/launches.h); both precisions
+// ... and in fp32 where the grid is too small for the chains (below 6 M cells the alternative is the plain one-chain sequence, and an
+// fp32 pair needs half the LDS of an fp64 one: all pairs of a 2048^2 launch are resident at once) -- rising bubble fp32 2048^2
+// (BASELINE configs[4]) 0.146 against 0.161 ms/step; in fp64 the same grid loses 10 % to the pairs (profiles/r06_forms_sweep.txt)
+inline bool chains_by_size(const vof2d_ctx* h) { return (long)h->g.nx * h->g.ny >= 6000000L && h->g.nx >= 2 * 1024; }
+inline int tm_choice_by_rule(const vof2d_ctx* h, double gas_share) {
+  const long cells = (long)(h->g.ihi - h->g.ilo + 1) * h->g.ny;
+  return (gas_share >= kTmGasShare || cells >= kTmAlwaysCells || (h->d.dtype == VOF_F32 && !chains_by_size(h))) ? 1 : 0;
+}
 inline bool tm_size_ok(const vof2d_ctx* h) {
   const long cells = (long)h->g.nx * h->g.ny;
   // (fp64 dam-break, k_tm + k_jacobi_pair against the plain sequence, ms/step: 1024^2 0.131 / 0.087, 1536^2 0.143 / 0.124, 2048^2 0.160 / 0.171,
@@ -235,7 +243,7 @@ inline bool halves_eligible(const vof2d_ctx* h, int K) {
   const int nj = h->d.jacobi_iters / 5, total = K * (2 + nj);
   // (a chain of few rows is short chunks and little else: 1024 x 8192 in two chains of 512 rows 0.319 -> 0.334 ms/step,
   // 2048 x 8192 0.583 -> 0.562, 8192 x 2048 0.604 -> 0.593)
-  const bool wanted = h->halves > 0 || (h->halves < 0 && (long)h->g.nx * h->g.ny >= 6000000L && h->g.nx >= 2 * 1024);
+  const bool wanted = h->halves > 0 || (h->halves < 0 && chains_by_size(h));
   return wanted && h->g.wall_lo && h->g.wall_hi && h->fuse_transport && h->tb >= 5 &&
          h->d.jacobi_iters % 10 == 0 && h->g.nx / halves_chains(h) - (total * kHalvesDrift + 1) / 2 >= 64;
 }

@@ -343,7 +343,7 @@ static void decide_batch_form_by_rule(vof2d_ctx* h) {
   if (hipEventSynchronize(h->ev_gas) != hipSuccess) { (void)hipGetLastError(); return; }
   const unsigned long long n = *h->h_gas;
   h->gas_share = (double)n / ((double)(h->g.ihi - h->g.ilo + 1) * (double)h->g.ny);
-  h->tm_choice = (h->gas_share >= kTmGasShare || (long)(h->g.ihi - h->g.ilo + 1) * h->g.ny >= kTmAlwaysCells) ? 1 : 0;
+  h->tm_choice = tm_choice_by_rule(h, h->gas_share);
   h->tm_decided = true;
   if (getenv("VOF2D_DEBUG")) fprintf(stderr, "[vof2d] batch form by rule: %.3f of the cells are gas -> %s\n", h->gas_share, h->tm_choice ? "k_tm" : "chains / plain");
 }

@@ -154,11 +154,12 @@ def test_batch_forms_are_timed_again_and_switching_changes_no_value(hip_api):
 
 
 def test_batch_form_follows_a_rule_on_the_state(hip_api):
-    """The default (fuse_tm = -1): which batch form a large fp64 full domain runs is a function of the state -- the share
-    of exact-zero cells of F when the handle first batches steps -- not of a stopwatch: two fresh handles agree, a
-    dam-break (5/6 gas) runs k_tm + k_jacobi_pair, a rising bubble (2 % gas) the chains -- up to 20 M cells; beyond, the pair
-    kernels whatever the grid holds --, and where the rule does not
-    apply (fp32, small grids) the counter says so.  Replacing F makes the handle look again."""
+    """The default (fuse_tm = -1): which batch form a large full domain runs is a function of the state -- the share
+    of exact-zero cells of F when the handle first batches steps (counted when set_init_F replaces F) -- not of a stopwatch: two
+    fresh handles agree, a dam-break (5/6 gas) runs k_tm + k_jacobi_pair, a rising bubble (2 % gas) the chains -- up to 16 M
+    cells; beyond, the pair kernels whatever the grid holds (round 6: 4096^2 included) --, in fp32 the pair kernels also where the
+    grid is too small for the chains (2048^2 bubble fp32 = BASELINE configs[4]), and where the rule does not apply (small grids)
+    the counter says so.  Replacing F makes the handle look again."""
     n = 4096
     a = engine(hip_api, n, n, "f64", "f32", ic=1)
     b = engine(hip_api, n, n, "f64", "f32", ic=1)
@@ -169,12 +170,24 @@ def test_batch_form_follows_a_rule_on_the_state(hip_api):
     assert a.get_param("gas_share") == b.get_param("gas_share") and 0.8 < a.get_param("gas_share") < 0.85
     assert a.get_counter("tm_steps") == b.get_counter("tm_steps") >= 32 and a.get_counter("halves_steps") == 0
     b.close()
-    a.set_init_F(2)                                   # the same handle, now a bubble: the rule looks at the new F
+    t0 = a.get_counter("tm_steps")
+    a.set_init_F(2)                                   # the same handle, now a bubble: the rule looks at the new F -- 16.8 M cells: still the pairs
     a.step(40)
-    assert a.get_counter("tm_choice") == 0 and a.get_param("gas_share") < 0.05
-    assert a.get_counter("halves_steps") >= 16
+    assert a.get_counter("tm_choice") == 1 and a.get_param("gas_share") < 0.05 and a.get_counter("tm_steps") >= t0 + 32
     a.close()
-    g = engine(hip_api, 5120, 5120, "f64", "f32", ic=2)   # from 20 M cells on the pair kernels win whatever the grid holds
+    a = engine(hip_api, 3072, 3072, "f64", "f32", ic=1)   # 9.4 M cells: the gas share decides
+    a.step(40)
+    assert a.get_counter("tm_choice") == 1 and a.get_counter("tm_steps") >= 32
+    a.set_init_F(2)
+    a.step(40)
+    assert a.get_counter("tm_choice") == 0 and a.get_param("gas_share") < 0.05 and a.get_counter("halves_steps") >= 16
+    a.close()
+    for dtype, want in (("f32", 1), ("f64", 0)):      # 4.2 M cells, bubble: too small for the chains -- fp32 runs the pairs, fp64 the plain sequence
+        g = engine(hip_api, 2048, 2048, dtype, "f32", ic=2)
+        g.step(40)
+        assert g.get_counter("tm_choice") == want and (g.get_counter("tm_steps") >= 32) == bool(want) and g.get_counter("halves_steps") == 0, dtype
+        g.close()
+    g = engine(hip_api, 5120, 5120, "f64", "f32", ic=2)   # from 16 M cells on the pair kernels win whatever the grid holds
     g.step(36)
     assert g.get_counter("tm_choice") == 1 and g.get_param("gas_share") < 0.05 and g.get_counter("tm_steps") >= 32
     g.close()

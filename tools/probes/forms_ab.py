@@ -15,7 +15,7 @@ rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 api = hip_api()
 kw = {"dt": 1e-6} if n > 4096 else {}
 forms = (("default", {}), ("k_tm + pairs", {"fuse_tm": 1, "jacobi_pair": 2}), ("k_tm, two tb launches", {"fuse_tm": 1, "jacobi_pair": 0}), ("chains / plain", {"fuse_tm": 0}))
-if dtype == "f32":
+if dtype == "f32" and os.environ.get("VOF2D_FORMS_VEC4"):      # (needs the -DVOF_PAIR_VEC4 experiment build)
     forms += (("k_tm + pairs, 4 per lane", {"fuse_tm": 1, "jacobi_pair": 2, "pair_vec4": 1}), ("k_tm (4 per lane), tb", {"fuse_tm": 1, "jacobi_pair": 0, "pair_vec4": 1}))
 engs = []
 for name, knobs in forms:
