@@ -25,6 +25,9 @@ STATE = ("F", "u", "v", "p")
 MODE5 = ("F", "u_star", "v_star", "rhs", "p")
 
 
+PARAMS = []     # --param knob=value: set on every STRIP handle (not on the full domain that feeds its halos)
+
+
 def strip_costs_pairs(api, nx, dtype, dt, parts, W, steps, skip=3):
     """The same for overlap mode 5 (the strips run k_jacobi_pair and k_tm, vof_step_tm_piece): ms per MIDDLE step of each
     strip's own kernels, its halos of F, u*, v*, rhs, p refreshed after every step from a full domain driven through the
@@ -36,6 +39,8 @@ def strip_costs_pairs(api, nx, dtype, dt, parts, W, steps, skip=3):
         full = Engine(api, make_desc(api, nx, nx, dtype, "f32", device=0, dt=dt))
         rows = stored_rows(nx, own, W)
         s = Engine(api, make_desc(api, nx, nx, dtype, "f32", rows=rows, own=own, device=0, dt=dt))
+        for kv in PARAMS:
+            s.set_param(kv.split("=")[0], float(kv.split("=")[1]))
 
         def refresh(fields):
             for f in fields:                     # what the neighbours would send
@@ -98,7 +103,9 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--pairs", action="store_true", help="overlap mode 5: the strips run k_jacobi_pair and k_tm (middle steps of a call)")
+    ap.add_argument("--param", action="append", default=[], help="knob=value set on every strip handle (e.g. tm_rows=52)")
     a = ap.parse_args()
+    PARAMS.extend(a.param)
     costs_of = strip_costs_pairs if a.pairs else strip_costs
     from vof2d import _abi
     from vof2d._lib import hip_api
