@@ -540,10 +540,11 @@ def balance_strips(a, comm, solver, make_solver, rank, world, nx):
     """Strips do not cost the same: rows of gas take the sweeps' zero shortcuts, the liquid and the interface do not (and
     GPUs differ a little).  Time each rank's strip on the equal partition, re-cut the rows so that every rank gets the
     same share of the cost, and start again from the initial condition.  Results do not depend on the partition.
-    The probe times the rank's own kernels on VALID data (the kernels are data dependent: zero shortcuts, division
-    tiers -- stale halos would feed them garbage rows): one kernel-only step, timed on the device, then a full halo
-    exchange before the next one (a deep halo covers exactly one step).  Waiting for neighbours is not in the figure, or
-    every rank would read the slowest rank's time.  A failure on one rank is agreed on before anybody changes partition.
+    The probe (StripSolver.probe_cost) times the rank's own kernels -- in mode 5 the pair kernels of a middle step, which weigh
+    the liquid differently from the four-kernel step -- on VALID data (the kernels are data dependent: zero shortcuts,
+    division tiers -- stale halos would feed them garbage rows): one kernel-only step, timed on the device, then a full
+    halo exchange before the next one (a deep halo covers exactly one step).  Waiting for neighbours is not in the figure,
+    or every rank would read the slowest rank's time.  A failure on one rank is agreed on before anybody changes partition.
     Either carrier (comm: an EnvComm beside the library's own RCCL communicator, or a TorchComm).  Returns the solver to
     time -- a new one, from the initial condition again."""
     if not ((world > 1 or os.environ.get("VOF2D_BENCH_TEST_BALANCE")) and not a.no_balance):   # (env: self-test of this block with one rank)
@@ -554,13 +555,7 @@ def balance_strips(a, comm, solver, make_solver, rank, world, nx):
         cost, failed = 0.0, 0.0
         try:
             with _StdoutToStderr():
-                samples = []
-                for _k in range(10):
-                    solver.eng.timer_start()
-                    solver.eng.step(1)
-                    samples.append(solver.eng.timer_stop())   # ms of this rank's stream
-                    solver.exchange()
-                cost = sum(samples[2:]) / len(samples[2:])
+                cost = solver.probe_cost(10, 2, a.overlap)    # ms of this rank's stream per step of the kernels the timed run will launch
         except Exception as exc:
             print("[bench] rank %d: cost probe failed (%r)" % (rank, exc), file=sys.stderr)
             failed = 1.0

@@ -278,7 +278,8 @@ class StripSolver:
         if self.world == 1:
             return
         if self.exchange_kind == "native":
-            bit = {"F": _abi.VOF_XCHG_F, "u": _abi.VOF_XCHG_U, "v": _abi.VOF_XCHG_V, "p": _abi.VOF_XCHG_P}
+            bit = {"F": _abi.VOF_XCHG_F, "u": _abi.VOF_XCHG_U, "v": _abi.VOF_XCHG_V, "p": _abi.VOF_XCHG_P,
+                   "u_star": _abi.VOF_XCHG_US, "v_star": _abi.VOF_XCHG_VS, "rhs": _abi.VOF_XCHG_RHS}
             self.eng.comm_exchange(sum(bit[f] for f in fields))
             return
         with self._ctx():          # (ordered behind the kernels on the solver's stream)
@@ -328,6 +329,40 @@ class StripSolver:
         works += self._exchange_async(("F",))
         for w in works:
             w.wait()
+
+    def probe_cost(self, n=10, skip=2, overlap=True):
+        """ms per step of THIS rank's kernels (device-timed on the handle's stream: no waiting for neighbours in the figure), on
+        valid data: one kernel-only step, then a full halo exchange before the next (the kernels are data dependent -- zero
+        shortcuts, division tiers --, stale halos would feed them garbage rows).  overlap == 5 on the GPU: the middle step of
+        mode 5 (k_jacobi_pair on all stored rows + k_tm on the owned rows, vof_step_tm_piece(1)) -- what a run in that mode
+        spends its time on; else the strip's plain step.  Either carrier.  Leaves the solver n + 2 steps into the run: the
+        caller starts again from a new one (bench.py: strips.balanced_partition)."""
+        e = self.eng
+        samples = []
+        if overlap == 5 and overlap is not True and self.on_gpu and self.world > 1:
+            with self._ctx():
+                if self.exchange_kind == "native":
+                    e.step_exchange(1, 1)            # the first step after set_init_F, with its exchanges
+                else:
+                    self._phased_step()
+                self._fresh = False
+                e.step_tm_piece(0)
+            self.exchange(EXCHANGED_MODE5 + EXCHANGED_PIECES)
+            for _ in range(n):
+                e.timer_start()
+                e.step_tm_piece(1)
+                samples.append(e.timer_stop())
+                self.exchange(("F", "p") + EXCHANGED_MODE5 + EXCHANGED_PIECES)
+            e.step_tm_piece(2)
+            self.exchange(EXCHANGED)
+        else:
+            for _ in range(n):
+                e.timer_start()
+                e.step(1)
+                samples.append(e.timer_stop())
+                self.exchange()
+            self._fresh = False
+        return sum(samples[skip:]) / len(samples[skip:])
 
     def _step_pieces(self, nsteps):
         """Overlap mode 5 on the GPU with the halos carried by torch.distributed instead of the library's own RCCL
