@@ -169,7 +169,9 @@ int vof_field_view(vof2d_handle h, const char* name, void** base, int64_t* pitch
                    int64_t* nrows);
 /* device-to-device copy of rows [g0, g1] of `name` from src into dst (same
  * nx, ny, dtype; rows must be stored by both).  Used for single-GPU strip
- * emulation; across GPUs the exchange is RCCL send/recv on vof_field_view. */
+ * emulation; across GPUs the exchange is RCCL send/recv on vof_field_view.
+ * Asynchronous and ordered on both handles: the copy follows everything enqueued
+ * on src so far, and everything enqueued on src or dst afterwards follows the copy. */
 int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t g0, int32_t g1);
 
 /* ---- display fields (2dvof.py:458-492; full-domain handles only) ----

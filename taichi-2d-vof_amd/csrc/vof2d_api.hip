@@ -653,7 +653,11 @@ int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t 
   const size_t off_s = (size_t)(g0 - src->d.row_lo) * src->g.pitch * src->esz;
   const size_t off_d = (size_t)(g0 - dst->d.row_lo) * dst->g.pitch * dst->esz;
   const size_t bytes = (size_t)(g1 - g0 + 1) * src->g.pitch * src->esz;
-  // order: after src's pending work, on dst's stream
+  // order, both ways: the copy runs on dst's stream after src's pending work, and whatever src enqueues next runs after
+  // the copy -- a strip's next launches overwrite rows in place (p: the second five-sweep launch or the copy-back of an
+  // odd launch count; rhs: k_tm) that a neighbour's pending copy may still have to read.  (Until round 6 only the first
+  // half held: the differential fuzz of tests/test_fuzz_gpu.py met the other one in 2 of 1700 emulated strip runs,
+  // both with five sweeps per step -- the shortest way from a copy to the next in-place write of p.)
   HIPCHK(dst, hipEventRecord(src->ev1, src->stream));
   HIPCHK(dst, hipStreamWaitEvent(dst->stream, src->ev1, 0));
   HIPCHK(dst, hipMemcpyAsync(reinterpret_cast<char*>(dst->fld[id]) + off_d,
@@ -663,6 +667,10 @@ int vof_copy_rows(vof2d_handle dst, vof2d_handle src, const char* name, int32_t 
     HIPCHK(dst, hipMemcpyAsync(reinterpret_cast<char*>(dst->fld[fF2]) + off_d,
                                reinterpret_cast<char*>(src->fld[fF]) + off_s, bytes, hipMemcpyDeviceToDevice,
                                dst->stream));
+  if (src->stream != dst->stream) {
+    HIPCHK(dst, hipEventRecord(dst->ev1, dst->stream));
+    HIPCHK(dst, hipStreamWaitEvent(src->stream, dst->ev1, 0));
+  }
   if (dst->g.wall_lo && dst->g.wall_hi) {  // a full domain: the rows' neighbours' ghost cells may no longer mirror them
     if (id == fF) { dst->f_ghosts_dirty = true; if (dst->fuse_tm == -1) { dst->tm_decided = false; dst->gas_pending = false; } }
     if (id == fMX || id == fMY) dst->alt_dirty = true;
