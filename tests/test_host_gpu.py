@@ -132,6 +132,12 @@ def test_exchange_mode5_in_fp32_and_with_more_sweeps(own, dtype, iters):
     _loopback_worker("mode5", own[0], own[1], dtype, iters)
 
 
+def test_exchange_modes_4_and_5_on_random_strips():
+    """The two deterministic exchange modes on strips, grids, precisions, sweep counts, chunk knobs and call lengths drawn from a
+    seed (tests/_loopback_worker.py fuzz; a campaign of hundreds of cases: profiles/r06_fuzz.md)."""
+    _loopback_worker("fuzz", int(os.environ.get("VOF_FUZZ_SEED", "20261003")), 10)
+
+
 def test_command_line_residual_terminated_solve(tmp_path):
     """2dvof.py --jacobi-tol / --jacobi-crit (extension): the main loop :513-528 with vof_solve_p in place of
     the ten fixed sweeps runs headless and reports like the reference."""
