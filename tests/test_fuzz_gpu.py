@@ -53,13 +53,18 @@ KNOBS = {
 }
 
 
-def draw_case(seed, large=0.03):
+def draw_case(seed, large=0.03, huge=0.0):
     """Everything a case is made of, from its seed: a dict the replay needs nothing else for.  large: share of grids of 0.3-2 M
     cells (several chunk rows and tile columns of the pair kernels, chains of launches; the oracle needs seconds for those)."""
     rng = np.random.default_rng(seed)
     dtype = "f64" if rng.random() < 0.7 else "f32"
     shape = rng.choice(["tiny", "small", "square", "wide", "tall", "medium"], p=[0.1, 0.2, 0.25, 0.15, 0.1, 0.2])
-    if rng.random() < large:
+    if rng.random() < huge:   # (what the rule of vof_step gives the pair kernels / the chains by itself: from 4 M / 6 M cells, nx >= 2048)
+        shape = "large"
+        nx, ny = int(rng.integers(2048, 3100)), int(rng.integers(1960, 3100))
+        if rng.random() < 0.3:
+            ny = nx
+    elif rng.random() < large:
         shape = "large"
         nx, ny = int(rng.integers(520, 1500)), int(rng.integers(520, 1400))
         if rng.random() < 0.5:
@@ -485,6 +490,7 @@ if __name__ == "__main__":
     ap.add_argument("--log", default=None)
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this much wall time (0: run all cases)")
     ap.add_argument("--large", type=float, default=0.03, help="share of grids of 0.3-2 M cells")
+    ap.add_argument("--huge", type=float, default=0.0, help="share of grids of 4-9 M cells with nx >= 2048 (the sizes the rule of vof_step acts on)")
     ap.add_argument("--strips", action="store_true", help="the strip cases (library against library) instead of the call sequences")
     args = ap.parse_args()
     from vof2d import _abi
@@ -501,7 +507,7 @@ if __name__ == "__main__":
             case = draw_strip_case(args.seed + k)
             why, text = run_strip_case(hip, case), describe_strip(case)
         else:
-            case = draw_case(args.seed + k, args.large)
+            case = draw_case(args.seed + k, args.large, args.huge)
             why, text = run_case(hip, oracle, case), describe(case)
         ran += 1
         if why:
