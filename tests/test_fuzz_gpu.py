@@ -104,7 +104,7 @@ def draw_case(seed, large=0.03, huge=0.0):
     budget = max(44 if shape == "large" else 6, min(budget, 140))
     nops = int(rng.integers(3, 9))
     for _ in range(nops):
-        kind = rng.choice(["step", "step", "step", "bigstep", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p"])
+        kind = rng.choice(["step", "step", "step", "bigstep", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile"])
         if kind == "step":
             ops.append(("step", int(rng.integers(1, 13))))
         elif kind == "bigstep":
@@ -127,6 +127,8 @@ def draw_case(seed, large=0.03, huge=0.0):
             ops.append(("sweeps", int(rng.choice([1, 2, 5, 10, 13, 20, 25]))))
         elif kind == "solve":
             ops.append(("solve", int(rng.choice([10, 25, 40])), int(rng.choice([3, 5, 10])), str(rng.choice(["abs", "rel"]))))
+        elif kind == "profile":
+            ops.append(("profile", int(rng.choice([1, 2, 5, 18, 35]))))
         else:
             ops.append(("tiny_p", int(rng.integers(0, 1 << 30))))
     # keep the oracle's work bounded: scale the step counts down to the budget
@@ -226,6 +228,12 @@ def run_case(hip_api, oracle_api, case):
                 for ph in (0, 1, 2):
                     a.step_phase(ph)
                 b.step(1)
+            elif op[0] == "profile":     # the in-situ profiler replays the handle's launch sequence eagerly: the state advances all the same
+                if a.api.prefix == "vof_":
+                    a.profile_steps(op[1])
+                else:
+                    a.step(op[1])
+                b.step(op[1])
             elif op[0] == "set":
                 rng = np.random.default_rng(op[2])
                 f = op[1]
@@ -469,7 +477,7 @@ def test_the_generator_is_deterministic_and_the_replay_runs_on_the_oracle(oracle
     kinds = set()
     for k in range(400):
         kinds.update(o[0] for o in draw_case(SEED0 + k)["ops"])
-    assert kinds == {"step", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p"}
+    assert kinds == {"step", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile"}
     done = 0
     for k in range(60):
         case = draw_case(SEED0 + k)
