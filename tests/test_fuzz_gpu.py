@@ -104,7 +104,7 @@ def draw_case(seed, large=0.03, huge=0.0):
     budget = max(44 if shape == "large" else 6, min(budget, 140))
     nops = int(rng.integers(3, 9))
     for _ in range(nops):
-        kind = rng.choice(["step", "step", "step", "bigstep", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile"])
+        kind = rng.choice(["step", "step", "step", "bigstep", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows"])
         if kind == "step":
             ops.append(("step", int(rng.integers(1, 13))))
         elif kind == "bigstep":
@@ -129,6 +129,10 @@ def draw_case(seed, large=0.03, huge=0.0):
             ops.append(("solve", int(rng.choice([10, 25, 40])), int(rng.choice([3, 5, 10])), str(rng.choice(["abs", "rel"]))))
         elif kind == "profile":
             ops.append(("profile", int(rng.choice([1, 2, 5, 18, 35]))))
+        elif kind == "istep":
+            ops.append(("istep", int(rng.choice([0, 1, 2, 7, 100, 1001]))))
+        elif kind == "setrows":
+            ops.append(("setrows", str(rng.choice(["F", "u", "v", "p"])), float(rng.random()), float(rng.random()), int(rng.integers(0, 1 << 30))))
         else:
             ops.append(("tiny_p", int(rng.integers(0, 1 << 30))))
     # keep the oracle's work bounded: scale the step counts down to the budget
@@ -136,12 +140,13 @@ def draw_case(seed, large=0.03, huge=0.0):
     if total > budget:
         ops = [("step", max(1, o[1] * budget // total)) if o[0] == "step" else o for o in ops]
     return dict(seed=seed, nx=nx, ny=ny, dtype=dtype, cast=str(rng.choice(["f32", "f32", "none"])), ic=int(rng.integers(1, 4)),
-                kw=kw, iters=iters, knobs=knobs, ops=ops)
+                kw=kw, iters=iters, knobs=knobs, ops=ops, eager=bool(rng.random() < 0.08))
 
 
 def describe(case):
-    return "seed %d: %dx%d %s cast=%s ic=%d iters=%d kw=%r knobs=%r ops=%r" % (
-        case["seed"], case["nx"], case["ny"], case["dtype"], case["cast"], case["ic"], case["iters"], case["kw"], case["knobs"], case["ops"])
+    return "seed %d: %dx%d %s cast=%s ic=%d iters=%d%s kw=%r knobs=%r ops=%r" % (
+        case["seed"], case["nx"], case["ny"], case["dtype"], case["cast"], case["ic"], case["iters"], " eager" if case.get("eager") else "",
+        case["kw"], case["knobs"], case["ops"])
 
 
 VERBS = ("cal_nu_rho", "get_normal_young", "advect_upwind", "set_BC", "solve_p_jacobi", "update_uv", "set_BC",
@@ -169,7 +174,8 @@ def run_case(hip_api, oracle_api, case):
     from vof2d.engine import VofError
     nx, ny, dtype = case["nx"], case["ny"], case["dtype"]
     try:
-        a = engine(hip_api, nx, ny, dtype, case["cast"], ic=case["ic"], jacobi_iters=case["iters"], **case["kw"])
+        a = engine(hip_api, nx, ny, dtype, case["cast"], ic=case["ic"], jacobi_iters=case["iters"],
+                   flags=1 if case.get("eager") else 0, **case["kw"])     # (VOF_FLAG_NO_GRAPH: every launch eager)
     except VofError:
         try:   # (a constant the exact division cannot take: both sides must refuse)
             engine(oracle_api, nx, ny, dtype, case["cast"], ic=case["ic"], jacobi_iters=case["iters"], **case["kw"])
@@ -249,6 +255,17 @@ def run_case(hip_api, oracle_api, case):
             elif op[0] == "sigma":
                 for e in (a, b):
                     e.set_param("sigma", op[1])
+            elif op[0] == "istep":       # (the step parity moved alone: the other sweep order, the other mask set of the work plan)
+                for e in (a, b):
+                    e.istep = op[1]
+            elif op[0] == "setrows":     # a band of rows overwritten (vof_set_rows)
+                rng = np.random.default_rng(op[4])
+                g0 = int(op[2] * (nx + 1))
+                g1 = min(nx + 1, g0 + int(op[3] * 40))
+                x = b.get(op[1], (g0, g1)).astype(np.float64)
+                x = np.clip(x + 0.2 * (rng.random(x.shape) < 0.2), 0, 1) if op[1] == "F" else x + 0.01 * rng.standard_normal(x.shape)
+                for e in (a, b):
+                    e.set(op[1], x, (g0, g1))
             elif op[0] == "knob":
                 a.set_param(op[1], op[2])
             elif op[0] == "sweeps":
@@ -477,7 +494,7 @@ def test_the_generator_is_deterministic_and_the_replay_runs_on_the_oracle(oracle
     kinds = set()
     for k in range(400):
         kinds.update(o[0] for o in draw_case(SEED0 + k)["ops"])
-    assert kinds == {"step", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile"}
+    assert kinds == {"step", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows"}
     done = 0
     for k in range(60):
         case = draw_case(SEED0 + k)
