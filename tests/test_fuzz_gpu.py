@@ -53,6 +53,48 @@ KNOBS = {
 }
 
 
+def _abuses():
+    """Calls the ABI must refuse with a status code -- no crash, no change of state (every entry point returns an int, no
+    exceptions or aborts across the ABI).  Each entry: name, f(api, handle, engine) -> status."""
+    import ctypes as C
+    buf = (C.c_double * 8)()
+    out = C.c_double()
+    i64 = C.c_int64()
+    i32 = C.c_int32()
+    return [
+        ("get_rows below the stored rows", lambda api, h, e: api.get_rows(h, b"F", e.row_lo - 1, e.row_lo + 1, buf, 64)),
+        ("get_rows above the stored rows", lambda api, h, e: api.get_rows(h, b"p", e.row_hi, e.row_hi + 3, buf, 64)),
+        ("get_rows reversed", lambda api, h, e: api.get_rows(h, b"u", 2, 1, buf, 64)),
+        ("get_rows with a short buffer", lambda api, h, e: api.get_rows(h, b"v", 0, 1, buf, 8)),
+        ("get_rows into NULL", lambda api, h, e: api.get_rows(h, b"F", 0, 0, None, (e.ny + 2) * 8)),
+        ("get_field of an unknown name", lambda api, h, e: api.get_field(h, b"vorticity", buf, 64)),
+        ("get_field with a NULL name", lambda api, h, e: api.get_field(h, None, buf, 64)),
+        ("set_rows with a wrong size", lambda api, h, e: api.set_rows(h, b"F", 0, 0, buf, 24)),
+        ("set_field from NULL", lambda api, h, e: api.set_field(h, b"u", None, 0)),
+        ("step(-1)", lambda api, h, e: api.step(h, -1)),
+        ("solve_p_jacobi(-3)", lambda api, h, e: api.solve_p_jacobi(h, -3)),
+        ("set_init_F(7)", lambda api, h, e: api.set_init_F(h, 7)),
+        ("set_init_F(0)", lambda api, h, e: api.set_init_F(h, 0)),
+        ("step_phase(1) out of order", lambda api, h, e: api.step_phase(h, 1)),
+        ("step_phase(5)", lambda api, h, e: api.step_phase(h, 5)),
+        ("set_param of an unknown name", lambda api, h, e: api.set_param(h, b"viscosity", 1.0)),
+        ("set_param with a NULL name", lambda api, h, e: api.set_param(h, None, 1.0)),
+        ("get_param of an unknown name", lambda api, h, e: api.get_param(h, b"gamma", C.byref(out))),
+        ("get_counter of an unknown name", lambda api, h, e: api.get_counter(h, b"launches", C.byref(i64))),
+        ("get_vis_field of an unknown image", lambda api, h, e: api.get_vis_field(h, b"pressure", buf, 64)),
+        ("get_vis_field with a short buffer", lambda api, h, e: api.get_vis_field(h, b"vof", buf, 64)),
+        ("interp_velocity with a short buffer", lambda api, h, e: api.interp_velocity(h, buf, 64)),
+        ("solve_p with an unknown criterion", lambda api, h, e: api.solve_p(h, 1e-6, 10, 5, 9, C.byref(i32), C.byref(out))),
+        ("solve_p with max_iters < 0", lambda api, h, e: api.solve_p(h, 1e-6, -1, 5, 0, C.byref(i32), C.byref(out))),
+        ("copy_rows from itself beyond its rows", lambda api, h, e: api.copy_rows(h, h, b"F", 0, e.nx + 7)),
+        ("copy_rows of an unknown field", lambda api, h, e: api.copy_rows(h, h, b"vorticity", 0, 1)),
+        ("a NULL handle", lambda api, h, e: api.step(None, 1)),
+    ]
+
+
+ABUSES = _abuses()
+
+
 def draw_case(seed, large=0.03, huge=0.0):
     """Everything a case is made of, from its seed: a dict the replay needs nothing else for.  large: share of grids of 0.3-2 M
     cells (several chunk rows and tile columns of the pair kernels, chains of launches; the oracle needs seconds for those)."""
@@ -104,7 +146,7 @@ def draw_case(seed, large=0.03, huge=0.0):
     budget = max(44 if shape == "large" else 6, min(budget, 140))
     nops = int(rng.integers(3, 9))
     for _ in range(nops):
-        kind = rng.choice(["step", "step", "step", "bigstep", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows"])
+        kind = rng.choice(["step", "step", "step", "bigstep", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows", "abuse"])
         if kind == "step":
             ops.append(("step", int(rng.integers(1, 13))))
         elif kind == "bigstep":
@@ -131,6 +173,8 @@ def draw_case(seed, large=0.03, huge=0.0):
             ops.append(("profile", int(rng.choice([1, 2, 5, 18, 35]))))
         elif kind == "istep":
             ops.append(("istep", int(rng.choice([0, 1, 2, 7, 100, 1001]))))
+        elif kind == "abuse":
+            ops.append(("abuse", int(rng.integers(0, len(ABUSES)))))
         elif kind == "setrows":
             ops.append(("setrows", str(rng.choice(["F", "u", "v", "p"])), float(rng.random()), float(rng.random()), int(rng.integers(0, 1 << 30))))
         else:
@@ -255,6 +299,12 @@ def run_case(hip_api, oracle_api, case):
             elif op[0] == "sigma":
                 for e in (a, b):
                     e.set_param("sigma", op[1])
+            elif op[0] == "abuse":       # an invalid call: refused with a status, the state as it was
+                what, call = ABUSES[op[1]]
+                for e in (a, b):
+                    rc = call(e.api, e.handle, e)
+                    if rc == 0:
+                        return "op %d: %s was accepted by %s" % (n, what, e.api.prefix)
             elif op[0] == "istep":       # (the step parity moved alone: the other sweep order, the other mask set of the work plan)
                 for e in (a, b):
                     e.istep = op[1]
@@ -487,6 +537,30 @@ def test_random_strip_decompositions_match_the_single_domain(hip_api):
     assert not failures, "%d cases diverge:\n" % len(failures) + "\n".join(failures)
 
 
+def _every_abuse_is_refused(api):
+    for nx, ny in ((20, 24), (300, 260)):
+        e = engine(api, nx, ny, "f64", "f32", ic=1)
+        e.step(2)
+        before = {f: e.get(f) for f in STATE}
+        for what, call in ABUSES:
+            assert call(api, e.handle, e) != 0, what
+        for f in STATE:
+            assert np.array_equal(before[f], e.get(f)), f
+        e.step(1)
+        e.close()
+
+
+@pytest.mark.gpu
+def test_invalid_calls_are_refused_and_change_nothing(hip_api):
+    """Every entry of ABUSES straight through the ABI (NULL pointers, rows outside the strip, short buffers, unknown names,
+    phases out of order ...): a status code each, no crash, the fields as they were, the next step runs."""
+    _every_abuse_is_refused(hip_api)
+
+
+def test_invalid_calls_are_refused_by_the_oracle_too(oracle_api):
+    _every_abuse_is_refused(oracle_api)
+
+
 def test_the_generator_is_deterministic_and_the_replay_runs_on_the_oracle(oracle_api):
     """CPU leg: the same seed draws the same case, and the replay itself (oracle against oracle, no knobs) goes through
     every kind of call without a divergence -- so a failure of the GPU leg is the library's."""
@@ -494,7 +568,7 @@ def test_the_generator_is_deterministic_and_the_replay_runs_on_the_oracle(oracle
     kinds = set()
     for k in range(400):
         kinds.update(o[0] for o in draw_case(SEED0 + k)["ops"])
-    assert kinds == {"step", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows"}
+    assert kinds == {"step", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows", "abuse"}
     done = 0
     for k in range(60):
         case = draw_case(SEED0 + k)
