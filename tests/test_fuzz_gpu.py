@@ -6,8 +6,13 @@ combinations nobody chose -- odd sizes with forced batch forms, chunk lengths th
 changed between batches, fields overwritten between chained batches, verbs between fused steps -- and replays the
 reference's semantics (the oracle) beside the library through the same ABI calls.
 
+Three more legs: random strip decompositions (2-6 uneven strips, three drivers) against the single domain, library against library;
+invalid calls straight through the ABI (refused with a status, the state untouched); and -- in tests/_loopback_worker.py fuzz --
+the captured RCCL exchange on random looped-back strips.  What the campaigns found: profiles/r06_fuzz.md.
+
     VOF_FUZZ_SEED   first seed (default 20261003)       VOF_FUZZ_CASES   cases of the default test (default 36)
-    python tests/test_fuzz_gpu.py --seed S --cases N [--log FILE]     a campaign outside pytest (same generator)
+    python tests/test_fuzz_gpu.py --seed S --cases N [--seconds T] [--log FILE] [--large P] [--huge P] [--strips]
+        a campaign outside pytest (same generators; --large / --huge: share of grids of 0.3-2 M / 4-9 M cells)
 """
 import os
 import sys
