@@ -18,7 +18,12 @@ def timed(e, steps=200):
 
 
 keep = []
-for k in range(10):
+if os.environ.get("SPREAD_DUMMY_FIRST"):     # something else takes the process's first big allocation
+    dummy = Engine(api, make_desc(api, int(os.environ["SPREAD_DUMMY_FIRST"]), int(os.environ["SPREAD_DUMMY_FIRST"]), "f64", "f32", device=0))
+    dummy.set_init_F(1); dummy.step(2); dummy.sync()
+    if os.environ.get("SPREAD_DUMMY_FREE"):
+        dummy.close()
+for k in range(int(os.environ.get("SPREAD_ENGINES", "10"))):
     e = Engine(api, make_desc(api, n, n, "f64", "f32", device=0))
     e.set_init_F(1); e.step(60); e.sync()
     a, b = timed(e), timed(e)
