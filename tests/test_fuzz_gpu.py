@@ -151,7 +151,7 @@ def draw_case(seed, large=0.03, huge=0.0):
     budget = max(44 if shape == "large" else 6, min(budget, 140))
     nops = int(rng.integers(3, 9))
     for _ in range(nops):
-        kind = rng.choice(["step", "step", "step", "bigstep", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows", "abuse"])
+        kind = rng.choice(["step", "step", "step", "bigstep", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows", "abuse", "norms"])
         if kind == "step":
             ops.append(("step", int(rng.integers(1, 13))))
         elif kind == "bigstep":
@@ -180,6 +180,8 @@ def draw_case(seed, large=0.03, huge=0.0):
             ops.append(("istep", int(rng.choice([0, 1, 2, 7, 100, 1001]))))
         elif kind == "abuse":
             ops.append(("abuse", int(rng.integers(0, len(ABUSES)))))
+        elif kind == "norms":
+            ops.append(("norms", int(rng.choice([1, 2, 3, 5, 6, 10, 11, 17, 20])), int(rng.choice([0, 0, 1, 4, 5, 10, 13]))))
         elif kind == "setrows":
             ops.append(("setrows", str(rng.choice(["F", "u", "v", "p"])), float(rng.random()), float(rng.random()), int(rng.integers(0, 1 << 30))))
         else:
@@ -304,6 +306,16 @@ def run_case(hip_api, oracle_api, case):
             elif op[0] == "sigma":
                 for e in (a, b):
                     e.set_param("sigma", op[1])
+            elif op[0] == "norms":       # sweeps whose last one reduces max|p_new - p| and max|p_new| (lane maxima -> __shfl_down -> atomicMax)
+                # (op[1] sweeps on a rhs built now, then op[2] more on the same rhs -- the two calls of a residual-terminated solve;
+                #  sweeps without a build on anything else are outside the contract: the oracle re-forms rhs from its rho array)
+                for k, (cnt, build) in enumerate(((op[1], True), (op[2], False))):
+                    if cnt == 0:
+                        continue
+                    ra, rb = a.jacobi_sweeps_norms(cnt, build), b.jacobi_sweeps_norms(cnt, build)
+                    if ra != rb and not (np.isnan(ra).any() or np.isnan(rb).any()):
+                        return "op %d %r, call %d: norms %r against %r" % (n, op, k, ra, rb)
+                names = STATE      # (the library forms rho in registers for this rhs: the rho / nu arrays belong to the verbs)
             elif op[0] == "abuse":       # an invalid call: refused with a status, the state as it was
                 what, call = ABUSES[op[1]]
                 for e in (a, b):
@@ -573,7 +585,7 @@ def test_the_generator_is_deterministic_and_the_replay_runs_on_the_oracle(oracle
     kinds = set()
     for k in range(400):
         kinds.update(o[0] for o in draw_case(SEED0 + k)["ops"])
-    assert kinds == {"step", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows", "abuse"}
+    assert kinds == {"step", "verbs", "reader", "phases", "set", "sigma", "knob", "sweeps", "solve", "tiny_p", "profile", "istep", "setrows", "abuse", "norms"}
     done = 0
     for k in range(60):
         case = draw_case(SEED0 + k)
