@@ -554,6 +554,48 @@ def test_random_strip_decompositions_match_the_single_domain(hip_api):
     assert not failures, "%d cases diverge:\n" % len(failures) + "\n".join(failures)
 
 
+@pytest.mark.gpu
+def test_handles_on_concurrent_host_threads(hip_api):
+    """One handle per host thread (one host thread per handle; ctypes releases the GIL inside a call): four threads
+    create, step (graph captures, batch forms, chains), overwrite and read their own handles at the same time, several rounds;
+    every thread's fields equal those of the same sequence run alone afterwards."""
+    import threading
+    specs = [(448, 400, "f64", 1, {"fuse_tm": 1, "overlap_halves": 0}), (300, 333, "f32", 2, {"fuse_tm": 1, "jacobi_pair": 2}),
+             (700, 260, "f64", 3, {"fuse_tm": 0, "overlap_halves": 2, "batch_steps": 8}), (96, 130, "f64", 2, {})]
+
+    def run(spec, out, k):
+        nx, ny, dtype, ic, knobs = spec
+        try:
+            e = engine(hip_api, nx, ny, dtype, "f32", ic=ic)
+            for name, v in knobs.items():
+                e.set_param(name, v)
+            for n in (1, 40, 7):
+                e.step(n)
+            u = e.get("u")
+            u[3:9, 2:7] += 0.01
+            e.set("u", u)
+            e.step(33)
+            out[k] = {f: e.get(f) for f in STATE}
+            e.close()
+        except Exception as exc:      # (reported by the main thread)
+            out[k] = exc
+
+    for _ in range(3):
+        got = [None] * len(specs)
+        threads = [threading.Thread(target=run, args=(sp, got, k)) for k, sp in enumerate(specs)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for k, sp in enumerate(specs):
+            alone = [None]
+            run(sp, alone, 0)
+            assert not isinstance(got[k], Exception), (sp, got[k])
+            assert not isinstance(alone[0], Exception), (sp, alone[0])
+            for f in STATE:
+                assert np.array_equal(got[k][f], alone[0][f], equal_nan=True), (sp, f)
+
+
 def _every_abuse_is_refused(api):
     for nx, ny in ((20, 24), (300, 260)):
         e = engine(api, nx, ny, "f64", "f32", ic=1)
