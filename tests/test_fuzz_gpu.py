@@ -596,6 +596,39 @@ def test_handles_on_concurrent_host_threads(hip_api):
                 assert np.array_equal(got[k][f], alone[0][f], equal_nan=True), (sp, f)
 
 
+@pytest.mark.gpu
+def test_create_step_destroy_leaves_no_device_memory_behind(hip_api):
+    """Handles come and go (every batch form captured, chains with their extra streams and events, a strip with a looped-back
+    communicator's worth of graphs is test_host_gpu's business): after 60 create / step / destroy cycles the device has the memory
+    it had after the first few, and the last handle still equals the first one's results."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+
+    def free_bytes():
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    def cycle(k):
+        nx, ny = (448, 400) if k % 3 else (700, 260)
+        e = engine(hip_api, nx, ny, "f64" if k % 2 else "f32", "f32", ic=1 + k % 3)
+        e.set_param("fuse_tm", 1 if k % 3 else 0)
+        e.set_param("overlap_halves", 0 if k % 3 else 2)
+        e.set_param("batch_steps", 8)
+        e.step(41)
+        out = e.get("F")
+        e.close()
+        return out
+
+    first = [cycle(k) for k in range(6)]
+    base = free_bytes()
+    for k in range(6, 60):
+        last = cycle(k)
+        if k >= 54:
+            assert np.array_equal(last, first[k - 54]), k       # (k and k - 54 draw the same case)
+    assert base - free_bytes() < (64 << 20), (base, free_bytes())
+
+
 def _every_abuse_is_refused(api):
     for nx, ny in ((20, 24), (300, 260)):
         e = engine(api, nx, ny, "f64", "f32", ic=1)
