@@ -629,6 +629,37 @@ def test_create_step_destroy_leaves_no_device_memory_behind(hip_api):
     assert base - free_bytes() < (64 << 20), (base, free_bytes())
 
 
+@pytest.mark.gpu
+def test_handles_on_a_caller_stream_and_two_handles_on_one_stream(hip_api):
+    """vof_create with the caller's stream (the library then creates none of its own for the step; the chains' extra streams only
+    ever run inside graphs launched on it): two handles sharing ONE caller stream, stepped alternately through every batch form, equal
+    the same handles on streams of their own."""
+    import ctypes as C
+    from vof2d.engine import Engine, make_desc
+    hip = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0      # hipStreamNonBlocking
+    specs = [(448, 400, "f64", 1, {"fuse_tm": 1, "overlap_halves": 0}), (700, 260, "f32", 3, {"fuse_tm": 0, "overlap_halves": 2, "batch_steps": 8})]
+    shared, own = [], []
+    for nx, ny, dtype, ic, knobs in specs:
+        for group, stream in ((shared, st.value), (own, None)):
+            e = Engine(hip_api, make_desc(hip_api, nx, ny, dtype, "f32"), stream=stream)
+            e.set_init_F(ic)
+            for k, v in knobs.items():
+                e.set_param(k, v)
+            group.append(e)
+    for n in (1, 40, 3, 18, 33):
+        for e in shared + own:
+            e.step(n)
+    for a, b in zip(shared, own):
+        for f in STATE + SCRATCH:
+            assert np.array_equal(a.get(f), b.get(f), equal_nan=True), f
+        assert a.get_counter("courant_violations") == b.get_counter("courant_violations")
+    for e in shared + own:
+        e.close()
+    assert hip.hipStreamDestroy(st) == 0
+
+
 def _every_abuse_is_refused(api):
     for nx, ny in ((20, 24), (300, 260)):
         e = engine(api, nx, ny, "f64", "f32", ic=1)
