@@ -221,7 +221,22 @@ def exchange_mode5_equals_pieces_plus_copies(hip_api, own, dtype="f64", iters=10
             ref.step_tm_piece(2); loop(("p", "u", "v", "F"))
         assert e.istep == ref.istep
         assert e.comm_info()[1] == 1, "exchange graph capture unavailable (RCCL %d)" % e.comm_info()[0]
-        if resync_first and e.istep == 1:
+        if e.istep == 1:
+            # The communicator's first step ran as overlap mode 1: p travels under the first sweep, u and v under the second, and
+            # a looped-back neighbour's rows are a translate of the strip's own -- the halo rows change VALUE under the kernels that
+            # read them (between real neighbours they are rewritten with identical values), so the rows within one step's reach of
+            # an interior edge depend on timing (native_rccl_exchange_loopback; seen once in some twenty runs of this test).  What
+            # does not: every halo ends up holding the final owned rows next to it, the rows deeper in equal the reference.  The
+            # comparison proper starts from the state this step left.
+            for f in ("F", "u", "v", "p"):
+                got = e.get(f, rows)
+                if not wall_lo:
+                    assert np.array_equal(got[lo - W:lo], got[lo:lo + W], equal_nan=True), (own, f, "lower halo after the first step")
+                if not wall_hi:
+                    assert np.array_equal(got[hi + 1:hi + 1 + W], got[hi - W + 1:hi + 1], equal_nan=True), (own, f, "upper halo after the first step")
+                a, b = (lo if wall_lo else lo + W), (hi + 1 if wall_hi else hi + 1 - W)
+                if b > a:
+                    assert np.array_equal(got[a:b], ref.get(f, rows)[a:b], equal_nan=True), (own, f, "rows away from the edges after the first step")
             _resync(e, ref, rows)
             continue
         if resync_first and not all(bool(np.isfinite(ref.get(f, rows)).all()) for f in ("F", "u", "v", "p")):
